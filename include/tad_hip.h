@@ -1,0 +1,214 @@
+/*
+ * tad_hip.h -- C ABI of libtad_hip.so: hand-written gfx950 (MI355X) kernels for the
+ * TimeAutoDiff hot path (denoiser training step, reverse-diffusion sampler, mixed-type
+ * VAE forward/backward).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float32 data unless stated otherwise;
+ *     tensors are row-major with an explicit leading dimension (ld*) in elements;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work on it, never
+ *     synchronise and never allocate;
+ *   - return value: TAD_OK or an error code; tad_last_error() gives the message of the
+ *     calling thread's last failure;
+ *   - `prec` selects the matrix-core operand type: TAD_F32 (v_mfma_f32_32x32x2_f32,
+ *     exact fp32 products) or TAD_BF16 (v_mfma_f32_32x32x16_bf16, operands rounded to
+ *     bf16, fp32 accumulation).  Everything outside the matrix products is fp32.
+ *
+ * Each entry point names the reference code it replaces (paths relative to the
+ * TimeAutoDiff checkout).  The reference has no FFI layer of its own: these are the
+ * ATen calls its nn.Module forwards / autograd / optimizer dispatch on this path.
+ */
+#ifndef TAD_HIP_H
+#define TAD_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tad_stream_t;
+
+enum { TAD_OK = 0, TAD_ERR_INVALID = 1, TAD_ERR_LAUNCH = 2 };
+enum { TAD_F32 = 0, TAD_BF16 = 1 };
+enum { TAD_ACT_NONE = 0, TAD_ACT_RELU = 1 };
+enum { TAD_CELL_LSTM = 0, TAD_CELL_GRU = 1 };
+
+int tad_abi_version(void);
+const char* tad_last_error(void);
+
+/* ------------------------------------------------------------------ linear family
+ * nn.Linear forward: Y[M,N] = act(X[M,K] W[N,K]^T + bias + bias2 + residual).
+ * Replaces every nn.Linear / FeedForward on the path: DIFF.py:57-63, 141, 155-164,
+ * 184, 188-194; VAE.py:80-86, 122-133, 143-145; and the input projections inside
+ * nn.LSTM / nn.GRU (DIFF.py:182, 189; VAE.py:119-120).  bias, bias2 ([N]) and residual
+ * ([M,N], row stride ld_res; may alias Y, e.g. the `x + cond_output(...)` sum of
+ * DIFF.py:216) may be NULL. */
+int tad_linear_fwd(int prec, int64_t M, int64_t N, int64_t K, const float* X, int64_t ldx, const float* W,
+                   int64_t ldw, const float* bias, const float* bias2, const float* residual, int64_t ld_res,
+                   float* Y, int64_t ldy, int act, tad_stream_t stream);
+
+/* autograd of nn.Linear wrt its input: dX[M,K] = dY[M,N] W[N,K] (+ dX if accumulate);
+ * if relu_of != NULL the result is zeroed where relu_of[m,k] <= 0 (backward of the
+ * ReLU that produced this layer's input, e.g. DIFF.py:62, 179, 193; VAE.py:129). */
+int tad_linear_bwd_data(int prec, int64_t M, int64_t N, int64_t K, const float* dY, int64_t ldy, const float* W,
+                        int64_t ldw, float* dX, int64_t ldx, const float* relu_of, int64_t ld_relu,
+                        int accumulate, tad_stream_t stream);
+
+/* autograd of nn.Linear wrt its weight: dW[N,K] += dY[M,N]^T X'[M,K].  Always
+ * accumulates (float atomics across M-slabs).  If T > 0 the rows of X are read
+ * time-shifted inside windows of T rows: X'[b*T+t] = X[b*T+t+tshift] when
+ * 0 <= t+tshift < T, else 0 -- the h_{t-1} operand of the recurrent weight gradient
+ * in BPTT (autograd of DIFF.py:182, 189; VAE.py:119-120). */
+int tad_linear_bwd_weight(int prec, int64_t M, int64_t N, int64_t K, const float* dY, int64_t ldy,
+                          const float* X, int64_t ldx, float* dW, int64_t ldw, int64_t T, int64_t tshift,
+                          tad_stream_t stream);
+
+/* Column sums: out_sum[n] += sum_m dY[m,n]; if out_wsum != NULL also
+ * out_wsum[n] += sum_m dY[m,n] * row_scale[m*row_scale_stride] * scale_mul.
+ * Bias gradients of every nn.Linear / RNN and the weight gradient of the
+ * Linear(1 -> H/2) inside PositionalEncoding (DIFF.py:141-145). */
+int tad_colsum(int64_t M, int64_t N, const float* dY, int64_t ldy, const float* row_scale,
+               int64_t row_scale_stride, float scale_mul, float* out_sum, float* out_sum2, float* out_wsum,
+               tad_stream_t stream);
+
+/* ------------------------------------------------------------------ recurrent family
+ * Per-direction arguments of the persistent LSTM / GRU sequence kernels.  xproj holds
+ * the input-side pre-activations x_t W_ih^T (+ b_ih, and + b_hh for LSTM) for all
+ * time steps; the kernel adds h_{t-1} W_hh^T, applies the gate nonlinearities and
+ * walks T steps with h (and c) resident on chip. */
+typedef struct {
+  const float* xproj;   /* [B,T,G*H], row stride ld_xproj (G = 4 LSTM, 3 GRU) */
+  int64_t ld_xproj;
+  const void* w_packed; /* from tad_rnn_pack_weights (forward image) */
+  const float* b_hh;    /* GRU: recurrent bias [3H]; LSTM: NULL */
+  float* out;           /* h_t -> out[(b*T+t)*ld_out + u], u < H */
+  int64_t ld_out;
+  float* stash;         /* training: [B,T,S*H], S = 5 (i,f,g,o,c) LSTM / 4 (r,z,n,W_hn h+b_hn) GRU; NULL = inference */
+  int32_t reverse;      /* 0: t = 0..T-1, 1: t = T-1..0 */
+  int32_t pad_;
+} tad_rnn_dir_t;
+
+/* nn.LSTM / nn.GRU forward over one layer, ndir (1 or 2) independent directions or
+ * heads in one launch (DIFF.py:182 -> 220, DIFF.py:189 -> 215, VAE.py:119-120 -> 154-155). */
+int tad_rnn_fwd(int cell, int prec, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
+                tad_stream_t stream);
+
+typedef struct {
+  const float* dout;      /* grad wrt h_t outputs, row stride ld_dout */
+  int64_t ld_dout;
+  const float* stash;     /* written by tad_rnn_fwd */
+  const float* out;       /* forward outputs h_t (GRU reads h_{t-1}); row stride ld_out */
+  int64_t ld_out;
+  const void* w_packed_t; /* from tad_rnn_pack_weights (backward image) */
+  float* dgates;          /* LSTM: [B,T,4H] grads of the pre-activations; GRU: [B,T,3H] input-side (r,z,n) */
+  float* dgates_h;        /* GRU: [B,T,3H] hidden-side (r,z,r*n-part); LSTM: NULL */
+  int64_t ld_dgates;      /* row stride of dgates and dgates_h (>= G*H) */
+  int32_t reverse;
+  int32_t pad_;
+} tad_rnn_bwd_dir_t;
+
+/* BPTT through one LSTM / GRU layer (autograd of the calls above): emits the
+ * pre-activation gradients; the weight/bias/input gradients follow from them with
+ * tad_linear_bwd_weight / tad_colsum / tad_linear_bwd_data. */
+int tad_rnn_bwd(int cell, int prec, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_bwd_dir_t* dirs,
+                tad_stream_t stream);
+
+/* Bytes of ONE packed image of a recurrent weight matrix W_hh[G*H,H]. */
+int64_t tad_rnn_packed_bytes(int prec, int64_t H, int G);
+/* Re-lay W_hh[G*H,H] (row stride H) into the MFMA-fragment-ordered images the
+ * sequence kernels stream: packed_fwd for h W_hh^T, packed_bwd for dgates W_hh.
+ * Either output may be NULL. */
+int tad_rnn_pack_weights(int prec, int64_t H, int G, const float* w_hh, void* packed_fwd, void* packed_bwd,
+                         tad_stream_t stream);
+
+/* ------------------------------------------------------------------ elementwise family
+ * add_noise (DIFF.py:102-118; get_gp_covariance DIFF.py:97-100 is the identity):
+ * x_noisy[b,:] = sqrt(alphas[i[b]]) x0[b,:] + sqrt(1-alphas[i[b]]) noise[b,:];
+ * also writes i_f[b*T+t] = (float) i[b] (the `i` tensor of DIFF.py:254).  row = T*K. */
+int tad_add_noise(int64_t B, int64_t T, int64_t K, const float* x0, const float* noise, const int32_t* i_idx,
+                  const float* alphas, float* x_noisy, float* i_f, tad_stream_t stream);
+
+/* One reverse-diffusion update (DIFF.py:348-351), in place on x:
+ * x = c1*(x - c2*pred) + c3*z;  if last: x = c1*(x - c2*pred) again.
+ * c1 = 1/sqrt(1-beta), c2 = beta/sqrt(1-alpha), c3 = sqrt(beta). */
+int tad_sampler_update(int64_t n, float* x, const float* pred, const float* z, float c1, float c2, float c3,
+                       int last, tad_stream_t stream);
+
+/* Denoiser loss (DIFF.py:259-260) and its gradient: loss_sum[0] += sum (pred-target)^2,
+ * dpred = grad_scale * (pred - target)  (grad_scale = 2/numel of the GLOBAL batch). */
+int tad_mse_loss(int64_t n, const float* pred, const float* target, float grad_scale, float* dpred,
+                 float* loss_sum, tad_stream_t stream);
+
+/* compute_sine_cosine (DIFF.py:14-32, VAE.py:24-42) with num_terms = 8:
+ * out[r, j*8+k] = sin(2^k pi x[r,j]), out[r, 8n + j*8+k] = cos(...). */
+int tad_sincos_features(int64_t rows, int n_nums, const float* x, int64_t ldx, float* out, int64_t ldo,
+                        tad_stream_t stream);
+
+/* Embedding lookups of Embedding_data.forward (DIFF.py:66-75, VAE.py:89-98):
+ * out[r, d*E + e] = tables[(tab_off[d] + (int)x[r,d]) * E + e], d < n_disc.
+ * Codes are clamped to [0, cards[d]-1] (the reference raises on out-of-range codes).
+ * tab_off / cards are HOST arrays of n_disc (<= 64) entries, copied into the launch. */
+int tad_embed_fwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* tables,
+                  const int32_t* tab_off, const int32_t* cards, float* out, int64_t ldo, tad_stream_t stream);
+/* ... and its autograd: dtables[(tab_off[d]+code)*E + e] += dout[r, d*E+e]. */
+int tad_embed_bwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* dout, int64_t ldo,
+                  float* dtables, const int32_t* tab_off, const int32_t* cards, tad_stream_t stream);
+
+/* PositionalEncoding.forward (DIFF.py:143-146): out[r, :L] = w[:]*(t[r]*inv_max) + b[:],
+ * out[r, L+j] = sin(t[r]*scale[j] + shift[j]); L = H/2, j < H-L.  t[r] = t[r*t_stride]. */
+int tad_posenc_fwd(int64_t rows, int H, const float* t, int64_t t_stride, float inv_max, const float* w,
+                   const float* b, const float* scale, const float* shift, float* out, int64_t ldo,
+                   tad_stream_t stream);
+
+/* nn.SiLU (DIFF.py:58, VAE.py:81) forward / backward. */
+int tad_silu_fwd(int64_t n, const float* z, float* a, tad_stream_t stream);
+int tad_silu_bwd(int64_t n, const float* z, const float* da, float* dz, tad_stream_t stream);
+
+/* nn.LayerNorm over the last dim D (DIFF.py:183, 221), eps 1e-5; mean_rstd[r] = {mean, rstd}. */
+int tad_layernorm_fwd(int64_t rows, int D, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                      float eps, float* y, int64_t ldy, float* mean_rstd, tad_stream_t stream);
+int tad_layernorm_bwd(int64_t rows, int D, const float* dy, int64_t lddy, const float* x, int64_t ldx,
+                      const float* gamma, const float* mean_rstd, float* dx, int64_t lddx, float* dgamma,
+                      float* dbeta, tad_stream_t stream);
+
+/* Row gather of the minibatch (DIFF.py:320, VAE.py:340-348): out[r,:] = src[idx[r],:]. */
+int tad_gather_rows(int64_t rows, int64_t row_len, const float* src, const int64_t* idx, float* out,
+                    tad_stream_t stream);
+
+/* torch.optim.Adam step on a flat buffer (DIFF.py:291, 325; VAE.py:295, 354), coupled
+ * L2 weight decay, bias correction for step number `step` (1-based). */
+int tad_adam_step(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, tad_stream_t stream);
+
+/* ------------------------------------------------------------------ VAE family
+ * reparametrize (VAE.py:147-150) + KLD partial sum (VAE.py:350-351):
+ * z = mu + eps*exp(lv/2); kld_sum[0] += sum(1 + lv - mu^2 - exp(lv)). */
+int tad_vae_reparam_fwd(int64_t n, const float* mu, const float* lv, const float* eps, float* z, float* kld_sum,
+                        tad_stream_t stream);
+/* dmu = dz + kld_scale*mu; dlv = dz*eps*0.5*exp(lv/2) - 0.5*kld_scale*(1-exp(lv));
+ * kld_scale = beta / numel (global). */
+int tad_vae_reparam_bwd(int64_t n, const float* dz, const float* mu, const float* lv, const float* eps,
+                        float kld_scale, float* dmu, float* dlv, tad_stream_t stream);
+
+/* Decoder heads epilogue + auto_loss (VAE.py:162-191 mask injection, 206-213 heads,
+ * 222-253 loss).  `heads` [rows, NH] holds the raw head pre-activations in the column
+ * order bins | cat_0 | ... | cat_{nc-1} | nums (NH = nb + sum cards + nn) and is
+ * overwritten IN PLACE with the reference-visible outputs (bins + mask offset,
+ * cat logits + mask offset on class 0, sigmoid(nums)*mask).  If dheads != NULL it
+ * receives d(loss)/d(raw pre-activations) with the mean reductions' denominators
+ * given by scale_bce, scale_ce (already divided by n_cats) and scale_mse.
+ * loss_parts[0] += sum BCE, [1] += sum MSE numerators, [2+j] += sum CE of cat j.
+ * mask/target are [rows, F] with F = nb + nc + nn.  cards is a HOST array of nc (<= 64)
+ * cardinalities. */
+int tad_vae_heads_loss(int64_t rows, int nb, int nc, int nn, const int32_t* cards, float* heads, int64_t ldh,
+                       const float* mask, const float* target, int64_t ldf, float scale_bce, float scale_ce,
+                       float scale_mse, float* dheads, float* loss_parts, tad_stream_t stream);
+
+/* inp = a + b and target = (a + b) * mask (VAE.py:331-336), elementwise over n. */
+int tad_vae_prepare(int64_t n, const float* resp, const float* cond, const float* mask, float* inp, float* target,
+                    tad_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAD_HIP_H */

@@ -1,0 +1,186 @@
+"""nn.LSTM / nn.GRU (batch_first, h0 = c0 = 0, no dropout) forward and BPTT.
+
+Oracle code: test infrastructure only.  Cell equations follow PyTorch 2.10's
+documented convention (gate rows stacked [i;f;g;o] for LSTM and [r;z;n] for
+GRU), which is what the reference's ``nn.LSTM`` (DIFF.py:182) and ``nn.GRU``
+(DIFF.py:189, VAE.py:119-120) evaluate.
+"""
+import numpy as np
+
+from .ops import sigmoid
+
+
+def _sfx(layer, reverse):
+    return f"_l{layer}" + ("_reverse" if reverse else "")
+
+
+# ----------------------------------------------------------------------------
+def lstm_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
+    B, T, _ = x.shape
+    H = Whh.shape[1]
+    dt = x.dtype
+    xp = x @ Wih.T + bih + bhh
+    h = np.zeros((B, H), dt)
+    c = np.zeros((B, H), dt)
+    hs = np.zeros((B, T, H), dt)
+    gates = np.zeros((B, T, 4 * H), dt)
+    cs = np.zeros((B, T, H), dt)
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        a = xp[:, t] + h @ Whh.T
+        i = sigmoid(a[:, :H])
+        f = sigmoid(a[:, H:2 * H])
+        g = np.tanh(a[:, 2 * H:3 * H])
+        o = sigmoid(a[:, 3 * H:])
+        c = f * c + i * g
+        h = o * np.tanh(c)
+        hs[:, t] = h
+        cs[:, t] = c
+        gates[:, t] = np.concatenate([i, f, g, o], -1)
+    return hs, (x, hs, cs, gates, reverse)
+
+
+def lstm_dir_bwd(Wih, Whh, cache, dhs, need_dx=True):
+    x, hs, cs, gates, reverse = cache
+    B, T, H = hs.shape
+    dt = x.dtype
+    da = np.zeros((B, T, 4 * H), dt)
+    hprev_all = np.zeros((B, T, H), dt)
+    dh_next = np.zeros((B, H), dt)
+    dc_next = np.zeros((B, H), dt)
+    fwd_order = list(range(T - 1, -1, -1) if reverse else range(T))
+    for n in range(T - 1, -1, -1):
+        t = fwd_order[n]
+        tp = fwd_order[n - 1] if n > 0 else None
+        c_prev = cs[:, tp] if tp is not None else np.zeros((B, H), dt)
+        h_prev = hs[:, tp] if tp is not None else np.zeros((B, H), dt)
+        hprev_all[:, t] = h_prev
+        i = gates[:, t, :H]
+        f = gates[:, t, H:2 * H]
+        g = gates[:, t, 2 * H:3 * H]
+        o = gates[:, t, 3 * H:]
+        tc = np.tanh(cs[:, t])
+        dh = dhs[:, t] + dh_next
+        do = dh * tc
+        dc = dh * o * (1 - tc * tc) + dc_next
+        di = dc * g
+        dg = dc * i
+        df = dc * c_prev
+        dc_next = dc * f
+        da_t = np.concatenate([di * i * (1 - i), df * f * (1 - f), dg * (1 - g * g), do * o * (1 - o)], -1)
+        da[:, t] = da_t
+        dh_next = da_t @ Whh
+    da2 = da.reshape(B * T, 4 * H)
+    dWih = da2.T @ x.reshape(B * T, -1)
+    dWhh = da2.T @ hprev_all.reshape(B * T, H)
+    db = da2.sum(0)
+    dx = (da2 @ Wih).reshape(x.shape) if need_dx else None
+    return dx, dWih, dWhh, db, db.copy()
+
+
+# ----------------------------------------------------------------------------
+def gru_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
+    B, T, _ = x.shape
+    H = Whh.shape[1]
+    dt = x.dtype
+    xp = x @ Wih.T + bih
+    h = np.zeros((B, H), dt)
+    hs = np.zeros((B, T, H), dt)
+    stash = np.zeros((B, T, 4 * H), dt)       # r, z, n, hp_n
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        hp = h @ Whh.T + bhh
+        r = sigmoid(xp[:, t, :H] + hp[:, :H])
+        z = sigmoid(xp[:, t, H:2 * H] + hp[:, H:2 * H])
+        n = np.tanh(xp[:, t, 2 * H:] + r * hp[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        hs[:, t] = h
+        stash[:, t] = np.concatenate([r, z, n, hp[:, 2 * H:]], -1)
+    return hs, (x, hs, stash, reverse)
+
+
+def gru_dir_bwd(Wih, Whh, cache, dhs, need_dx=True):
+    x, hs, stash, reverse = cache
+    B, T, H = hs.shape
+    dt = x.dtype
+    dxp = np.zeros((B, T, 3 * H), dt)
+    dhp = np.zeros((B, T, 3 * H), dt)
+    hprev_all = np.zeros((B, T, H), dt)
+    dh_next = np.zeros((B, H), dt)
+    fwd_order = list(range(T - 1, -1, -1) if reverse else range(T))
+    for k in range(T - 1, -1, -1):
+        t = fwd_order[k]
+        tp = fwd_order[k - 1] if k > 0 else None
+        h_prev = hs[:, tp] if tp is not None else np.zeros((B, H), dt)
+        hprev_all[:, t] = h_prev
+        r = stash[:, t, :H]
+        z = stash[:, t, H:2 * H]
+        n = stash[:, t, 2 * H:3 * H]
+        hpn = stash[:, t, 3 * H:]
+        dh = dhs[:, t] + dh_next
+        dn = dh * (1 - z)
+        dz = dh * (h_prev - n)
+        dan = dn * (1 - n * n)
+        dar = dan * hpn * r * (1 - r)
+        daz = dz * z * (1 - z)
+        dxp[:, t] = np.concatenate([dar, daz, dan], -1)
+        dhp_t = np.concatenate([dar, daz, dan * r], -1)
+        dhp[:, t] = dhp_t
+        dh_next = dh * z + dhp_t @ Whh
+    dxp2 = dxp.reshape(B * T, 3 * H)
+    dhp2 = dhp.reshape(B * T, 3 * H)
+    dWih = dxp2.T @ x.reshape(B * T, -1)
+    dWhh = dhp2.T @ hprev_all.reshape(B * T, H)
+    dbih = dxp2.sum(0)
+    dbhh = dhp2.sum(0)
+    dx = (dxp2 @ Wih).reshape(x.shape) if need_dx else None
+    return dx, dWih, dWhh, dbih, dbhh
+
+
+# ----------------------------------------------------------------------------
+_CELL = {"lstm": (lstm_dir_fwd, lstm_dir_bwd), "gru": (gru_dir_fwd, gru_dir_bwd)}
+
+
+def rnn_fwd(kind, sd, prefix, x, num_layers, bidirectional):
+    """Multi-layer (bi)directional RNN.  sd maps torch names (prefix +
+    'weight_ih_l0' ...) to arrays.  Returns (out [B,T,D*H], caches)."""
+    fwd, _ = _CELL[kind]
+    caches = []
+    inp = x
+    for layer in range(num_layers):
+        outs = []
+        lc = []
+        for rev in ([False, True] if bidirectional else [False]):
+            s = _sfx(layer, rev)
+            hs, cache = fwd(inp, sd[prefix + "weight_ih" + s], sd[prefix + "weight_hh" + s],
+                            sd[prefix + "bias_ih" + s], sd[prefix + "bias_hh" + s], rev)
+            outs.append(hs)
+            lc.append(cache)
+        inp = np.concatenate(outs, -1) if bidirectional else outs[0]
+        caches.append(lc)
+    return inp, caches
+
+
+def rnn_bwd(kind, sd, prefix, caches, dout, num_layers, bidirectional, grads, need_dx=True):
+    """BPTT through rnn_fwd.  Accumulates parameter grads into ``grads`` (dict by
+    torch name) and returns dx (or None)."""
+    _, bwd = _CELL[kind]
+    d = dout
+    for layer in range(num_layers - 1, -1, -1):
+        dirs = [False, True] if bidirectional else [False]
+        H = caches[layer][0][1].shape[-1]
+        dx_total = None
+        for di, rev in enumerate(dirs):
+            s = _sfx(layer, rev)
+            dh = d[..., di * H:(di + 1) * H] if bidirectional else d
+            want_dx = need_dx or layer > 0
+            dx, dWih, dWhh, dbih, dbhh = bwd(sd[prefix + "weight_ih" + s], sd[prefix + "weight_hh" + s],
+                                             caches[layer][di], dh, need_dx=want_dx)
+            grads[prefix + "weight_ih" + s] = dWih
+            grads[prefix + "weight_hh" + s] = dWhh
+            grads[prefix + "bias_ih" + s] = dbih
+            grads[prefix + "bias_hh" + s] = dbhh
+            if want_dx:
+                dx_total = dx if dx_total is None else dx_total + dx
+        d = dx_total
+    return d

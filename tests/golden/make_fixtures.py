@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the reference.
+
+Run in the build container only (the reference checkout is not available on
+the GPU box):  python tests/golden/make_fixtures.py [--ref /root/reference]
+
+The reference's hot-path modules import ``dataprovider`` which imports
+``pygrinder`` (not installed, unused on the path); an empty stand-in module is
+placed in ``sys.modules`` for the import.  Nothing of the reference is copied:
+the outputs are data only (inputs, random draws or their seeds, outputs,
+gradients, loss curves).
+
+Conventions shared with tests/fixture_util.py:
+  * synthetic inputs come from ``fixture_util.make_data`` (numpy, seeded);
+  * model weights come from ``torch.manual_seed(seed)`` followed by the model
+    constructor; small cases store the weights, the medium case stores per
+    tensor checksums so a re-created model can be verified;
+  * random draws inside the loops follow the reference's consumption order of
+    python ``random`` and torch's CPU generator and are replayed from seeds.
+"""
+import argparse
+import os
+import random
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import fixture_util as fu  # noqa: E402
+
+
+def import_reference(ref):
+    sys.dont_write_bytecode = True
+    stub = types.ModuleType("pygrinder")
+    for a in ("mcar", "seq_missing", "block_missing"):
+        setattr(stub, a, lambda *a, **k: None)
+    sys.modules["pygrinder"] = stub
+    sys.path.insert(0, ref)
+    import torch  # noqa
+    import DIFF
+    import VAE
+    return DIFF, VAE
+
+
+def sd_to_np(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def grads_to_np(model):
+    return {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def stats(a):
+    a64 = a.astype(np.float64).ravel()
+    return np.array([a64.sum(), np.sqrt((a64 ** 2).sum()), a64[:8].sum() if a64.size else 0.0])
+
+
+# ----------------------------------------------------------------------------
+def denoiser_case(DIFF, name, schema, H, E, T, B, K, seed, store_weights=True):
+    import torch
+    F = schema["n_bins"] + schema["n_cats"] + schema["n_nums"]
+    data = fu.make_data(schema, N=B, T=T, K=K, seed=seed, mask_kind="bern")
+    torch.manual_seed(seed)
+    model = DIFF.BiRNN_score(K, F, H, 2, 100, 8, E, schema["n_bins"], schema["n_cats"], schema["n_nums"],
+                             list(schema["cards"]))
+    sd0 = sd_to_np(model.state_dict())
+    g = torch.Generator().manual_seed(seed + 1)
+    t = torch.rand(B, T, 1, generator=g).sort(1)[0]
+    i_idx = torch.randint(0, 100, (B,), generator=g)
+    noise = torch.randn(B, T, K, generator=g)
+    x0 = torch.from_numpy(data["latent"])
+    cond = torch.from_numpy(data["cond"])
+    tinfo = torch.from_numpy(data["time_info"])
+    i = i_idx.view(-1, 1, 1).expand_as(x0[..., :1]).to(x0)
+    alpha = DIFF.alphas[i.long()].to(x0)
+    x_noisy = torch.sqrt(alpha) * x0 + torch.sqrt(1 - alpha) * noise
+    # check add_noise's arithmetic agrees (its own randn is replaced by ours)
+    orig = torch.randn_like
+    torch.randn_like = lambda x: noise
+    try:
+        xn2, n2 = DIFF.add_noise(x0, t, i)
+    finally:
+        torch.randn_like = orig
+    assert torch.equal(xn2, x_noisy) and torch.equal(n2, noise)
+    pred = model(x_noisy, t, i, tinfo, cond, None)
+    loss = torch.mean((pred - noise) ** 2)
+    loss.backward()
+    grads = grads_to_np(model)
+    out = dict(meta=fu.pack_meta(dict(kind="denoiser", schema=schema, H=H, E=E, T=T, B=B, K=K, seed=seed,
+                                      store_weights=store_weights)),
+               t=t.numpy(), i_idx=i_idx.numpy(), noise=noise.numpy(), x_noisy=x_noisy.numpy(),
+               pred=pred.detach().numpy(), loss=np.float64(loss.item()))
+    if store_weights:
+        for k, v in sd0.items():
+            out["w/" + k] = v
+        for k, v in grads.items():
+            out["g/" + k] = v
+    else:
+        for k, v in sd0.items():
+            out["ws/" + k] = stats(v)
+        for k, v in grads.items():
+            out["gs/" + k] = stats(v)
+            out["gh/" + k] = v.ravel()[:64].copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", loss.item(), "params", sum(v.size for v in sd0.values()))
+
+
+# ----------------------------------------------------------------------------
+def vae_case(VAE, name, schema, H, E, L, T, B, seed, mask_kind):
+    import torch
+    F = schema["n_bins"] + schema["n_cats"] + schema["n_nums"]
+    data = fu.make_data(schema, N=B, T=T, K=L, seed=seed, mask_kind=mask_kind)
+    torch.manual_seed(seed)
+    ae = VAE.DeapStack(1, schema["n_bins"], schema["n_cats"], schema["n_nums"], list(schema["cards"]),
+                       F, H, 2, E, 8, L)
+    sd0 = sd_to_np(ae.state_dict())
+    g = torch.Generator().manual_seed(seed + 1)
+    eps = torch.randn(B, T, L, generator=g)
+    orig = torch.randn_like
+    torch.randn_like = lambda x: eps
+    try:
+        resp = torch.from_numpy(data["response"])
+        cond = torch.from_numpy(data["cond"])
+        mask = torch.from_numpy(data["mask"])
+        inp = resp + cond
+        target = inp * mask
+        out, z, mu, lv = ae(inp, mask, cond)
+    finally:
+        torch.randn_like = orig
+    disc, num = VAE.auto_loss(target, out, schema["n_bins"], schema["n_nums"], schema["n_cats"], list(schema["cards"]))
+    kld = -0.5 * torch.mean((1 + lv - mu.pow(2) - lv.exp()).mean(-1).mean())
+    beta = 0.1
+    loss = num + disc + beta * kld
+    loss.backward()
+    grads = grads_to_np(ae)
+    o = dict(meta=fu.pack_meta(dict(kind="vae", schema=schema, H=H, E=E, L=L, T=T, B=B, seed=seed,
+                                    mask_kind=mask_kind, beta=beta)),
+             eps=eps.numpy(), z=z.detach().numpy(), mu=mu.detach().numpy(), lv=lv.detach().numpy(),
+             loss=np.float64(loss.item()), disc=np.float64(float(disc)), num=np.float64(float(num)),
+             kld=np.float64(kld.item()))
+    if "bins" in out:
+        o["out/bins"] = out["bins"].detach().numpy()
+    if "cats" in out:
+        for j, c in enumerate(out["cats"]):
+            o[f"out/cats{j}"] = c.detach().numpy()
+    if "nums" in out:
+        o["out/nums"] = out["nums"].detach().numpy()
+    for k, v in sd0.items():
+        o["w/" + k] = v
+    for k, v in grads.items():
+        o["g/" + k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **o)
+    print(name, "loss", loss.item(), "params", sum(v.size for v in sd0.values()))
+
+
+# ----------------------------------------------------------------------------
+class _Parser:
+    def __init__(self, schema):
+        self.s = schema
+
+    def datatype_info(self):
+        return dict(n_bins=self.s["n_bins"], n_cats=self.s["n_cats"], n_nums=self.s["n_nums"],
+                    cards=list(self.s["cards"]))
+
+
+def diffusion_loop_case(DIFF, name, schema, H, T, K, N, steps, seed):
+    """train_diffusion for ``steps`` iterations then sample; emb_dim is the
+    reference's hard-coded 128 and the batch its hard-coded 100."""
+    import torch
+    data = fu.make_data(schema, N=N, T=T, K=K, seed=seed, mask_kind="ones")
+    dd = dict(parser=_Parser(schema), cond_train=torch.from_numpy(data["cond"]),
+              time_info_train=torch.from_numpy(data["time_info"]),
+              target_mask_train=torch.from_numpy(data["mask"]))
+    losses = []
+    orig = DIFF.get_loss
+
+    def rec(*a, **k):
+        l = orig(*a, **k)
+        losses.append(float(l.item()))
+        return l
+    DIFF.get_loss = rec
+    try:
+        random.seed(seed)
+        torch.manual_seed(seed)
+        model = DIFF.train_diffusion(torch.from_numpy(data["latent"]), None, dd, H, 2, 100, steps)
+    finally:
+        DIFF.get_loss = orig
+    sd1 = sd_to_np(model.state_dict())
+    # sampling with the trained model
+    Bs = 3
+    torch.manual_seed(seed + 7)
+    tgrid = torch.linspace(0, 1, T).view(1, -1, 1).repeat(Bs, 1, 1)
+    x = DIFF.sample(tgrid, Bs, T, K, 100, model, torch.from_numpy(data["time_info"][:Bs]),
+                    torch.from_numpy(data["cond"][:Bs]), None)
+    out = dict(meta=fu.pack_meta(dict(kind="diffusion_loop", schema=schema, H=H, T=T, K=K, N=N, steps=steps,
+                                      seed=seed, Bs=Bs)),
+               losses=np.array(losses), sample=x.numpy())
+    for k, v in sd1.items():
+        out["ws/" + k] = stats(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "losses", losses[:3], "...", losses[-1])
+
+
+def sampler_case(DIFF, name, schema, H, E, T, K, B, seed):
+    """sample() on a freshly initialised small model; keeps x after steps 99, 50, 1, 0."""
+    import torch
+    F = schema["n_bins"] + schema["n_cats"] + schema["n_nums"]
+    data = fu.make_data(schema, N=B, T=T, K=K, seed=seed, mask_kind="ones")
+    torch.manual_seed(seed)
+    model = DIFF.BiRNN_score(K, F, H, 2, 100, 8, E, schema["n_bins"], schema["n_cats"], schema["n_nums"],
+                             list(schema["cards"]))
+    sd0 = sd_to_np(model.state_dict())
+    kept = {}
+    calls = {"n": 0}
+    orig_fwd = model.forward
+
+    def fwd(x, *a, **k):
+        # x entering call number n is the state after reverse step 100-n
+        s_done = 100 - calls["n"]
+        if s_done in (99, 50, 1):
+            kept[s_done] = x.detach().numpy().copy()
+        calls["n"] += 1
+        return orig_fwd(x, *a, **k)
+    model.forward = fwd
+    torch.manual_seed(seed + 7)
+    tgrid = torch.linspace(0, 1, T).view(1, -1, 1).repeat(B, 1, 1)
+    x = DIFF.sample(tgrid, B, T, K, 100, model, torch.from_numpy(data["time_info"]),
+                    torch.from_numpy(data["cond"]), None)
+    out = dict(meta=fu.pack_meta(dict(kind="sampler", schema=schema, H=H, E=E, T=T, K=K, B=B, seed=seed)),
+               x_final=x.numpy(), x_after_99=kept[99], x_after_50=kept[50], x_after_1=kept[1])
+    for k, v in sd0.items():
+        out["w/" + k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "x_final norm", float(np.linalg.norm(x.numpy())))
+
+
+def vae_loop_case(VAE, name, schema, H, T, L, N, Nv, B, steps, seed, fn_name):
+    import torch
+    F = schema["n_bins"] + schema["n_cats"] + schema["n_nums"]
+    tr = fu.make_data(schema, N=N, T=T, K=L, seed=seed, mask_kind="bern")
+    va = fu.make_data(schema, N=Nv, T=T, K=L, seed=seed + 100, mask_kind="bern")
+    dd = dict(parser=_Parser(schema),
+              response_train=torch.from_numpy(tr["response"]), cond_train=torch.from_numpy(tr["cond"]),
+              target_mask_train=torch.from_numpy(tr["mask"]),
+              response_val=torch.from_numpy(va["response"]), cond_val=torch.from_numpy(va["cond"]),
+              target_mask_val=torch.from_numpy(va["mask"]))
+    random.seed(seed)
+    torch.manual_seed(seed)
+    fn = getattr(VAE, fn_name)
+    ae, latent, output, hist = fn(None, 1, H, 2, 2e-4, 1e-6, steps, B, 1, 1e-5, 0.1, 16, 8, L, "cpu", dd)
+    o = dict(meta=fu.pack_meta(dict(kind="vae_loop", schema=schema, H=H, T=T, L=L, N=N, Nv=Nv, B=B, steps=steps,
+                                    seed=seed, fn=fn_name, lr=2e-4, wd=1e-6, min_beta=1e-5, max_beta=0.1, E=16)),
+             train=np.array(hist["train"]), val=np.array(hist["val"]), latent=latent.numpy())
+    for k, v in sd_to_np(ae.state_dict()).items():
+        o["ws/" + k] = stats(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **o)
+    print(name, "train", hist["train"][:2], hist["train"][-1], "val", hist["val"][-1])
+
+
+def schedule_case(DIFF):
+    np.savez_compressed(os.path.join(HERE, "schedule.npz"), betas=DIFF.betas.numpy(), alphas=DIFF.alphas.numpy())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    a = ap.parse_args()
+    DIFF, VAE = import_reference(a.ref)
+    import torch
+    torch.set_num_threads(4)
+    S = fu.SCHEMAS
+    schedule_case(DIFF)
+    denoiser_case(DIFF, "den_numeric_small", S["numeric"], H=24, E=16, T=8, B=5, K=6, seed=11)
+    denoiser_case(DIFF, "den_mixed_small", S["mixed"], H=24, E=16, T=8, B=5, K=6, seed=12)
+    denoiser_case(DIFF, "den_metro_small", S["metro"], H=40, E=16, T=6, B=3, K=4, seed=13)
+    denoiser_case(DIFF, "den_numeric_h200", S["numeric"], H=200, E=128, T=24, B=4, K=6, seed=14,
+                  store_weights=False)
+    vae_case(VAE, "vae_numeric_small", S["numeric"], H=24, E=16, L=6, T=8, B=5, seed=21, mask_kind="ones")
+    vae_case(VAE, "vae_mixed_small", S["mixed"], H=24, E=16, L=6, T=8, B=5, seed=22, mask_kind="bern")
+    vae_case(VAE, "vae_metro_small", S["metro"], H=40, E=16, L=4, T=6, B=3, seed=23, mask_kind="forecast")
+    sampler_case(DIFF, "sampler_mixed_small", S["mixed"], H=24, E=16, T=8, K=6, B=3, seed=31)
+    diffusion_loop_case(DIFF, "diffloop_numeric", S["numeric"], H=16, T=6, K=4, N=128, steps=20, seed=41)
+    vae_loop_case(VAE, "vaeloop_mixed_val", S["mixed"], H=24, T=6, L=4, N=64, Nv=16, B=16, steps=30, seed=51,
+                  fn_name="train_autoencoder")
+    vae_loop_case(VAE, "vaeloop_mixed_train", S["mixed"], H=24, T=6, L=4, N=64, Nv=16, B=16, steps=30, seed=52,
+                  fn_name="train_autoencoder_best_train")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+"""Pin the numpy oracle against golden vectors produced by the reference itself
+(tests/golden/*.npz, written by tests/golden/make_fixtures.py).  CPU only."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_util as fu
+import oracle
+from oracle import denoiser, loops, ops, vae
+from oracle.denoiser import Schema
+
+TOL = 2e-5   # float32 oracle vs float32 reference: different summation orders only
+
+
+def _schema(meta):
+    s = meta["schema"]
+    return Schema(s["n_bins"], s["n_cats"], s["n_nums"], list(s["cards"]))
+
+
+def test_schedule():
+    z, _ = fu.load("schedule")
+    betas, alphas = ops.schedule(100)
+    assert fu.rel_err(betas, z["betas"]) < 1e-6
+    assert fu.rel_err(alphas, z["alphas"]) < 1e-6
+    assert abs(float(z["alphas"][0]) - 0.99998999) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["den_numeric_small", "den_mixed_small", "den_metro_small"])
+def test_denoiser_small(name):
+    z, meta = fu.load(name)
+    sch = _schema(meta)
+    sd = fu.sub(z, "w")
+    data = fu.make_data(meta["schema"], N=meta["B"], T=meta["T"], K=meta["K"], seed=meta["seed"], mask_kind="bern")
+    _, alphas = ops.schedule(100)
+    xn = ops.add_noise(data["latent"], z["i_idx"], z["noise"], alphas)
+    assert fu.rel_err(xn, z["x_noisy"]) < 1e-6
+    loss, pred, grads = denoiser.loss_and_grads(sd, data["latent"], z["t"], z["i_idx"], z["noise"],
+                                                data["time_info"], data["cond"], sch, alphas)
+    assert fu.rel_err(pred, z["pred"]) < TOL
+    assert abs(loss - float(z["loss"])) < TOL * abs(float(z["loss"]))
+    gref = fu.sub(z, "g")
+    assert set(gref) == set(grads), (set(gref) ^ set(grads))
+    assert not any(k.startswith("Emb_hidden") for k in grads)
+    for k in gref:
+        assert fu.rel_err(grads[k].reshape(gref[k].shape), gref[k]) < 5e-5, k
+
+
+def test_denoiser_h200_recreated_weights():
+    """Medium case: weights are re-created from the seed with plain torch modules in
+    the reference's constructor order and verified by checksum."""
+    from timeautodiff_amd import DIFF
+    z, meta = fu.load("den_numeric_h200")
+    sch = _schema(meta)
+    torch.manual_seed(meta["seed"])
+    sd_t = DIFF.init_denoiser_state(meta["K"], meta["H"], 2, 100, 8, meta["E"], sch.n_bins, sch.n_cats, sch.n_nums,
+                                    sch.cards)
+    sd = {k: v.numpy() for k, v in sd_t.items()}
+    ws = fu.sub(z, "ws")
+    assert set(ws) == set(sd)
+    for k in ws:
+        assert np.allclose(fu.stats(sd[k]), ws[k], rtol=1e-12, atol=1e-12), k
+    data = fu.make_data(meta["schema"], N=meta["B"], T=meta["T"], K=meta["K"], seed=meta["seed"], mask_kind="bern")
+    _, alphas = ops.schedule(100)
+    loss, pred, grads = denoiser.loss_and_grads(sd, data["latent"], z["t"], z["i_idx"], z["noise"],
+                                                data["time_info"], data["cond"], sch, alphas)
+    assert fu.rel_err(pred, z["pred"]) < TOL
+    gs = fu.sub(z, "gs")
+    gh = fu.sub(z, "gh")
+    assert set(gs) == set(grads)
+    for k in gs:
+        n = gs[k][1]
+        assert abs(np.linalg.norm(grads[k].astype(np.float64)) - n) < 1e-4 * max(n, 1e-12), k
+        head = grads[k].ravel()[:64]
+        assert np.max(np.abs(head - gh[k])) < 1e-4 * max(np.max(np.abs(grads[k])), 1e-12), k
+
+
+@pytest.mark.parametrize("name", ["vae_numeric_small", "vae_mixed_small", "vae_metro_small"])
+def test_vae_small(name):
+    z, meta = fu.load(name)
+    sch = _schema(meta)
+    sd = fu.sub(z, "w")
+    data = fu.make_data(meta["schema"], N=meta["B"], T=meta["T"], K=meta["L"], seed=meta["seed"],
+                        mask_kind=meta["mask_kind"])
+    inp = data["response"] + data["cond"]
+    total, res, grads = vae.loss_and_grads(sd, inp, data["mask"], data["cond"], z["eps"], np.float32(meta["beta"]), sch)
+    assert fu.rel_err(res["mu"], z["mu"]) < TOL
+    assert fu.rel_err(res["lv"], z["lv"]) < TOL
+    assert fu.rel_err(res["z"], z["z"]) < TOL
+    if sch.n_bins:
+        assert fu.rel_err(res["out"]["bins"], z["out/bins"]) < TOL
+    for j in range(sch.n_cats):
+        assert fu.rel_err(res["out"]["cats"][j], z[f"out/cats{j}"]) < TOL
+    if sch.n_nums:
+        assert fu.rel_err(res["out"]["nums"], z["out/nums"]) < TOL
+    assert abs(total - float(z["loss"])) < 1e-5 * abs(float(z["loss"]))
+    assert abs(res["parts"]["kld"] - float(z["kld"])) < 1e-5 * abs(float(z["kld"]))
+    assert abs(res["parts"]["mse"] - float(z["num"])) < 1e-5 * max(abs(float(z["num"])), 1e-9)
+    assert abs(res["parts"]["bce"] + res["parts"]["ce"] - float(z["disc"])) < 1e-5 * max(abs(float(z["disc"])), 1e-9)
+    gref = fu.sub(z, "g")
+    assert set(gref) == set(grads), (set(gref) ^ set(grads))
+    assert not any(k.startswith("time_encode") for k in grads)
+    for k in gref:
+        assert fu.rel_err(grads[k].reshape(gref[k].shape), gref[k]) < 5e-5, k
+
+
+def test_sampler_trajectory():
+    z, meta = fu.load("sampler_mixed_small")
+    sch = _schema(meta)
+    sd = fu.sub(z, "w")
+    B, T, K = meta["B"], meta["T"], meta["K"]
+    data = fu.make_data(meta["schema"], N=B, T=T, K=K, seed=meta["seed"], mask_kind="ones")
+    torch.manual_seed(meta["seed"] + 7)
+    x_T = torch.randn(B, T, K).numpy()
+    zs = {}
+    for s in range(99, -1, -1):
+        zs[s] = torch.randn(B, T, K).numpy()
+    betas, alphas = ops.schedule(100)
+    tgrid = torch.linspace(0, 1, T).view(1, -1, 1).repeat(B, 1, 1).numpy()
+    x, kept = loops.sample(sd, tgrid, data["time_info"], data["cond"], sch, x_T, zs, betas, alphas, keep=(99, 50, 1))
+    assert fu.rel_err(kept[99], z["x_after_99"]) < 1e-5
+    assert fu.rel_err(kept[50], z["x_after_50"]) < 1e-4
+    assert fu.rel_err(kept[1], z["x_after_1"]) < 1e-4
+    e_final = fu.rel_err(x, z["x_final"])
+    assert e_final < 1e-4
+    # the step-0 quirk (second application of the mean formula) is observable: a single
+    # update at step 0 is measurably further from the reference than the restated double update
+    pred, _ = denoiser.forward(sd, kept[1], tgrid, np.zeros((B, T, 1), np.float32), data["time_info"], data["cond"], sch)
+    once = ops.sampler_update(kept[1], pred, zs[0], betas[0], alphas[0], last=False)
+    twice = ops.sampler_update(kept[1], pred, zs[0], betas[0], alphas[0], last=True)
+    e_once, e_twice = fu.rel_err(once, z["x_final"]), fu.rel_err(twice, z["x_final"])
+    assert e_twice < 1e-5 and e_once > 5 * e_twice, (e_once, e_twice)
+
+
+def replay_diffusion_draws(N, T, K, steps, B=100):
+    """Random draws of train_diffusion's iterations in the reference's order
+    (DIFF.py:306, 317, 253, 108) from the already seeded generators."""
+    for _ in range(steps):
+        idx = random.sample(list(range(N)), B)
+        t = torch.rand(B, T, 1).sort(1)[0].numpy()
+        i = torch.randint(0, 100, size=(B,)).numpy()
+        noise = torch.randn(B, T, K).numpy()
+        yield dict(idx=idx, t=t, i=i, noise=noise)
+
+
+def test_diffusion_loss_curve():
+    from timeautodiff_amd import DIFF
+    z, meta = fu.load("diffloop_numeric")
+    sch = _schema(meta)
+    N, T, K, H, steps = meta["N"], meta["T"], meta["K"], meta["H"], meta["steps"]
+    data = fu.make_data(meta["schema"], N=N, T=T, K=K, seed=meta["seed"], mask_kind="ones")
+    random.seed(meta["seed"])
+    torch.manual_seed(meta["seed"])
+    sd = {k: v.numpy().copy() for k, v in
+          DIFF.init_denoiser_state(K, H, 2, 100, 8, 128, sch.n_bins, sch.n_cats, sch.n_nums, sch.cards).items()}
+    _, alphas = ops.schedule(100)
+    losses = loops.train_diffusion_steps(sd, data["latent"], data["time_info"], data["cond"], sch,
+                                         replay_diffusion_draws(N, T, K, steps), alphas)
+    ref = z["losses"]
+    assert len(losses) == len(ref)
+    assert np.max(np.abs(np.array(losses) - ref) / np.abs(ref)) < 1e-3
+    ws = fu.sub(z, "ws")
+    for k in ws:
+        if k.startswith("Emb_hidden"):
+            continue
+        assert abs(fu.stats(sd[k])[1] - ws[k][1]) < 1e-3 * max(ws[k][1], 1e-6), k
+
+
+@pytest.mark.parametrize("name,select", [("vaeloop_mixed_val", "val"), ("vaeloop_mixed_train", "train")])
+def test_vae_loss_curve(name, select):
+    from timeautodiff_amd import VAE
+    z, meta = fu.load(name)
+    sch = _schema(meta)
+    N, Nv, T, L, B, steps = meta["N"], meta["Nv"], meta["T"], meta["L"], meta["B"], meta["steps"]
+    tr = fu.make_data(meta["schema"], N=N, T=T, K=L, seed=meta["seed"], mask_kind="bern")
+    va = fu.make_data(meta["schema"], N=Nv, T=T, K=L, seed=meta["seed"] + 100, mask_kind="bern")
+    data = dict(response_train=tr["response"], cond_train=tr["cond"], target_mask_train=tr["mask"],
+                response_val=va["response"], cond_val=va["cond"], target_mask_val=va["mask"])
+    random.seed(meta["seed"])
+    torch.manual_seed(meta["seed"])
+    F = sch.n_bins + sch.n_cats + sch.n_nums
+    sd = {k: v.numpy().copy() for k, v in
+          VAE.init_vae_state(sch.n_bins, sch.n_cats, sch.n_nums, sch.cards, F, meta["H"], 2, meta["E"], 8, L).items()}
+
+    def draws():
+        for _ in range(steps):
+            idx = random.sample(list(range(N)), B)
+            e1 = torch.randn(B, T, L).numpy()
+            e2 = torch.randn(Nv, T, L).numpy()
+            yield dict(idx=idx, eps_train=e1, eps_val=e2)
+    hist, best, beta = loops.train_autoencoder_steps(sd, data, sch, draws(), meta["lr"], meta["wd"],
+                                                     meta["min_beta"], meta["max_beta"], select=select)
+    assert np.max(np.abs(np.array(hist["train"]) - z["train"]) / np.abs(z["train"])) < 1e-3
+    assert np.max(np.abs(np.array(hist["val"]) - z["val"]) / np.abs(z["val"])) < 1e-3
+    ws = fu.sub(z, "ws")
+    for k in ws:
+        assert abs(fu.stats(best[k])[1] - ws[k][1]) < 1e-3 * max(ws[k][1], 1e-6), k
+    # latent returned by the reference = sampled z of the full train set under the best weights
+    eps = torch.randn(N, T, L).numpy()
+    zl, _, _, _ = vae.encoder_fwd(best, tr["response"] + tr["cond"], eps, sch)
+    assert fu.rel_err(zl, z["latent"]) < 1e-3

@@ -1,0 +1,331 @@
+"""Drop-in for the reference's VAE.py hot path on MI355X.
+
+``DeapStack`` (encoder / decoder / forward), ``auto_loss`` and the two trainers
+``train_autoencoder`` / ``train_autoencoder_best_train`` keep the reference's names,
+signatures and return values; the arithmetic runs in libtad_hip.so.  Parameters are
+created by the same torch constructors in the same order as the reference
+(VAE.py:114-145), so seeded initial weights and state_dict keys coincide.
+"""
+import random
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .DIFF import _EmbeddingData
+from .dist import DataParallelPlan
+from .engine import VAEEngine, prec_of
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class DeapStack(nn.Module):
+    """Mixed-type sequence VAE (reference VAE.py:111-220).  ``time_encode`` exists only because
+    the reference constructs (and never uses) it."""
+
+    def __init__(self, channels, n_bins, n_cats, n_nums, cards, input_size, hidden_size, num_layers, cat_emb_dim,
+                 time_dim, lat_dim):
+        super().__init__()
+        self.cfg = dict(n_bins=n_bins, n_cats=n_cats, n_nums=n_nums, cards=list(cards), input_size=input_size,
+                        hidden_size=hidden_size, num_layers=num_layers, emb_dim=cat_emb_dim, time_dim=time_dim,
+                        lat_dim=lat_dim)
+        self.Emb = _EmbeddingData(input_size, cat_emb_dim, n_bins, n_cats, n_nums, cards)
+        self.time_encode = nn.Sequential(nn.Linear(time_dim, input_size), nn.ReLU(), nn.Linear(input_size, input_size))
+        self.encoder_mu = nn.GRU(input_size, hidden_size, num_layers, batch_first=True)
+        self.encoder_logvar = nn.GRU(input_size, hidden_size, num_layers, batch_first=True)
+        self.fc_mu = nn.Linear(hidden_size, lat_dim)
+        self.fc_logvar = nn.Linear(hidden_size, lat_dim)
+        self.decoder_mlp = nn.Sequential(nn.Linear(lat_dim, hidden_size), nn.ReLU(), nn.Linear(hidden_size, hidden_size))
+        self.Emb_decoder = _EmbeddingData(input_size, cat_emb_dim, n_bins, n_cats, n_nums, cards)
+        self.Emb_hidden_decoder = nn.Linear(input_size, hidden_size)
+        self.channels = channels
+        self.n_bins, self.n_cats, self.n_nums, self.cards = n_bins, n_cats, n_nums, cards
+        self.disc = n_bins + n_cats
+        self.bins_linear = nn.Linear(hidden_size, n_bins) if n_bins else None
+        self.cats_linears = nn.ModuleList([nn.Linear(hidden_size, card) for card in cards]) if n_cats else None
+        self.nums_linear = nn.Linear(hidden_size, n_nums) if n_nums else None
+        self._eng = None
+        self._eng_dtype = "fp32"
+        self.register_load_state_dict_post_hook(lambda m, keys: m.mark_params_changed())
+
+    # -- engine plumbing ----------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        prec_of(dtype)
+        if dtype != self._eng_dtype:
+            self._eng_dtype = dtype
+            self._eng = None
+        return self
+
+    def engine(self, dev=None) -> VAEEngine:
+        dev = torch.device(dev) if dev is not None else (self._eng.device if self._eng is not None else device)
+        if dev.type != "cuda":
+            raise RuntimeError("DeapStack runs only on an MI355X through libtad_hip.so; no GPU is visible "
+                               "(there is no CPU fallback)")
+        if self._eng is None or self._eng.device != dev or not self._eng.fp.owns(self):
+            self._eng = VAEEngine(self, dev, self._eng_dtype)
+        return self._eng
+
+    def mark_params_changed(self):
+        if self._eng is not None:
+            self._eng.fp.version += 1
+
+    def _dev_f32(self, a, eng):
+        return a.to(device=eng.device, dtype=torch.float32).contiguous()
+
+    # -- reference API ------------------------------------------------------
+    def encoder(self, x, *, eps=None):
+        """reference VAE.py:152-160 -> (emb, mu_z, logvar_z); the reparametrisation noise is drawn
+        with torch.randn_like on the device unless ``eps`` is given."""
+        eng = self.engine(x.device if x.is_cuda else None)
+        eng.fp.version += 1
+        x = self._dev_f32(x, eng)
+        B, T, _ = x.shape
+        if eps is None:
+            eps = torch.randn(B, T, eng.lat, device=eng.device)
+        z, mu, lv = eng.encoder(x, self._dev_f32(eps, eng), train=False)
+        return z.clone(), mu.clone(), lv.clone()
+
+    def decoder(self, latent_feature, mask=None, cond=None):
+        """reference VAE.py:193-215 -> dict with 'bins' / 'cats' / 'nums' (present when that
+        column type exists)."""
+        eng = self.engine(latent_feature.device if latent_feature.is_cuda else None)
+        eng.fp.version += 1
+        z = self._dev_f32(latent_feature, eng)
+        B, T, _ = z.shape
+        heads = eng.decoder(z, self._dev_f32(mask, eng), self._dev_f32(cond, eng) if cond is not None else None)
+        return eng.split_heads(heads, B, T)
+
+    def forward(self, x, mask, cond=None, *, eps=None):
+        emb, mu_z, logvar_z = self.encoder(x, eps=eps)
+        outputs = self.decoder(emb, mask, cond)
+        return outputs, emb, mu_z, logvar_z
+
+
+def init_vae_state(n_bins, n_cats, n_nums, cards, input_size, hidden_size, num_layers, emb_dim, time_dim, lat_dim):
+    """state_dict (CPU tensors) of a freshly constructed DeapStack under the current torch seed."""
+    m = DeapStack(1, n_bins, n_cats, n_nums, list(cards), input_size, hidden_size, num_layers, emb_dim, time_dim, lat_dim)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def auto_loss(inputs, reconstruction, n_bins, n_nums, n_cats, cards):
+    """reference VAE.py:222-253 on already-decoded outputs -> (disc_loss, num_loss) device scalars.
+    (The trainers use the fused head+loss kernel instead; this entry point exists for drivers
+    that call auto_loss directly.)"""
+    dev = inputs.device
+    if dev.type != "cuda":
+        raise RuntimeError("auto_loss runs on the GPU only")
+    B, L, F = inputs.shape
+    rows = B * L
+    parts = torch.zeros(2 + max(n_cats, 1), device=dev)
+    cols = []
+    if "bins" in reconstruction:
+        cols.append(reconstruction["bins"].reshape(rows, -1))
+    if "cats" in reconstruction:
+        cols += [c.reshape(rows, -1) for c in reconstruction["cats"]]
+    if "nums" in reconstruction:
+        cols.append(reconstruction["nums"].reshape(rows, -1))
+    heads = torch.cat(cols, dim=1).float().contiguous()
+    # the outputs already carry the mask offsets / sigmoid: evaluate the loss terms directly
+    ones = torch.ones(rows, F, device=dev)
+    nb = n_bins if "bins" in reconstruction else 0
+    nc = n_cats if "cats" in reconstruction else 0
+    disc = torch.zeros((), device=dev)
+    num = torch.zeros((), device=dev)
+    tgt = inputs.reshape(rows, F).float().contiguous()
+    if nb or nc:
+        sub = heads[:, :nb + sum(cards[:nc])].contiguous()
+        ops.vae_heads_loss(sub, ones, tgt, nb, nc, 0, list(cards[:nc]), 0, 0, 0, None, parts)
+        if nb:
+            disc = disc + parts[0] / (rows * nb)
+        if nc:
+            disc = disc + parts[2:2 + nc].sum() / (rows * nc)
+    if "nums" in reconstruction:
+        nums = heads[:, heads.shape[1] - n_nums:].contiguous()
+        t = tgt[:, n_bins + n_cats:n_bins + n_cats + n_nums].contiguous()
+        s = torch.zeros(1, device=dev)
+        ops.mse_loss(nums, t, 0.0, None, s)
+        num = s[0] / nums.numel()
+    return disc, num
+
+
+# ---------------------------------------------------------------------------
+class VAETrainer:
+    """Device-resident training state of the VAE (one process per GPU)."""
+
+    def __init__(self, ae: DeapStack, data_dict, *, batch_size, lr, weight_decay, dtype="fp32", process_group=None, dev=None):
+        ae.set_compute_dtype(dtype)
+        self.ae = ae
+        self.eng = eng = ae.engine(dev)
+        d = eng.device
+        f32 = dict(device=d, dtype=torch.float32)
+        n = lambda k: data_dict[k].to(**f32).contiguous() if data_dict.get(k) is not None else None  # noqa: E731
+        self.resp_tr, self.mask_tr, self.cond_tr = n("response_train"), n("target_mask_train"), n("cond_train")
+        self.resp_va, self.mask_va, self.cond_va = n("response_val"), n("target_mask_val"), n("cond_val")
+        self.N, self.T, self.F = self.resp_tr.shape
+        self.B = batch_size
+        self.lr, self.wd = lr, weight_decay
+        self.plan = DataParallelPlan(batch_size, process_group)
+        # inp = response + cond, target = inp * mask (reference VAE.py:331-336), once, on device
+        self.inp_tr = torch.empty_like(self.resp_tr)
+        self.tgt_tr = torch.empty_like(self.resp_tr)
+        ops.vae_prepare(self.resp_tr, self.cond_tr, self.mask_tr, self.inp_tr, self.tgt_tr)
+        self.inp_va = torch.empty_like(self.resp_va)
+        self.tgt_va = torch.empty_like(self.resp_va)
+        ops.vae_prepare(self.resp_va, self.cond_va, self.mask_va, self.inp_va, self.tgt_va)
+        self.Nv = self.resp_va.shape[0]
+        self.vplan = DataParallelPlan(self.Nv, process_group)
+        self.parts = torch.zeros(3 + max(eng.nc, 1), device=d)      # [bce, mse, ce_0.., kld] partial sums
+        nb = self.plan.local_count
+        ws = eng.ws
+        self.b_inp = ws.get("batch.inp", (nb, self.T, self.F))
+        self.b_tgt = ws.get("batch.tgt", (nb, self.T, self.F))
+        self.b_mask = ws.get("batch.mask", (nb, self.T, self.F))
+        self.b_cond = ws.get("batch.cond", (nb, self.T, self.F)) if self.cond_tr is not None else None
+        self.all_indices = list(range(self.N))
+
+    def _loss(self, rows, beta):
+        """Combine the (all-reduced) partial sums on the host -> python float total."""
+        p = self.parts.tolist()
+        nc = self.eng.nc
+        total, _ = self.eng.total_loss(p[:2 + nc], p[2 + max(nc, 1)], beta, rows)
+        return total
+
+    def train_step(self, beta, idx=None, eps=None):
+        """One optimizer step (reference VAE.py:322-354) -> train loss (python float)."""
+        eng, plan = self.eng, self.plan
+        d = eng.device
+        if idx is None:
+            idx = random.sample(self.all_indices, self.B)
+        if eps is None:
+            eps = torch.randn(self.B, self.T, eng.lat, device=d)
+        lo, hi = plan.lo, plan.hi
+        idx_d = torch.as_tensor(idx[lo:hi], dtype=torch.int64).to(d)
+        eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
+        ops.gather_rows(self.inp_tr, idx_d, self.b_inp)
+        ops.gather_rows(self.tgt_tr, idx_d, self.b_tgt)
+        ops.gather_rows(self.mask_tr, idx_d, self.b_mask)
+        if self.b_cond is not None:
+            ops.gather_rows(self.cond_tr, idx_d, self.b_cond)
+        rows = self.B * self.T
+        eng.fp.zero_grad()
+        self.parts.zero_()
+        nc = eng.nc
+        kld = self.parts[2 + max(nc, 1):]
+        z, mu, lv = eng.encoder(self.b_inp, eps_l, train=True, kld_sum=kld)
+        eng.decoder(z, self.b_mask, self.b_cond, target=self.b_tgt, scales=eng.loss_scales(rows), loss_parts=self.parts,
+                    train=True)
+        eng.backward(beta, rows)
+        plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.parts)
+        eng.fp.adam(self.lr, weight_decay=self.wd)
+        return self._loss(rows, beta)
+
+    def eval_loss(self, beta, eps=None):
+        """Full validation-set loss under the current weights (reference VAE.py:357-368)."""
+        eng, plan = self.eng, self.vplan
+        d = eng.device
+        if eps is None:
+            eps = torch.randn(self.Nv, self.T, eng.lat, device=d)
+        lo, hi = plan.lo, plan.hi
+        self.parts.zero_()
+        nc = eng.nc
+        kld = self.parts[2 + max(nc, 1):]
+        eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
+        z, mu, lv = eng.encoder(self.inp_va[lo:hi], eps_l, train=False, kld_sum=kld)
+        cond = self.cond_va[lo:hi] if self.cond_va is not None else None
+        eng.decoder(z, self.mask_va[lo:hi], cond, target=self.tgt_va[lo:hi], loss_parts=self.parts, train=False)
+        plan.all_reduce(self.parts)
+        return self._loss(self.Nv * self.T, beta)
+
+    def full_forward(self, eps=None):
+        """Forward of the whole training set (reference VAE.py:395-402) -> (output dict, latent)."""
+        eng = self.eng
+        d = eng.device
+        if eps is None:
+            eps = torch.randn(self.N, self.T, eng.lat, device=d)
+        z, mu, lv = eng.encoder(self.inp_tr, eps.to(device=d, dtype=torch.float32).contiguous(), train=False)
+        latent = z.clone()
+        heads = eng.decoder(latent, self.mask_tr, self.cond_tr)
+        return eng.split_heads(heads, self.N, self.T), latent
+
+
+def _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size, threshold, min_beta,
+           max_beta, emb_dim, time_dim, lat_dim, device, data_dict, select, dtype, process_group, noise_source,
+           progress):
+    info = data_dict["parser"].datatype_info()
+    n_bins, n_cats, n_nums, cards = info["n_bins"], info["n_cats"], info["n_nums"], info["cards"]
+    N, _, input_size = data_dict["response_train"].shape
+    ae = DeapStack(channels, n_bins, n_cats, n_nums, cards, input_size, hidden_size, num_layers, emb_dim, time_dim, lat_dim)
+    dev = torch.device(device) if device is not None else None
+    if dev is not None and dev.type != "cuda":
+        raise RuntimeError("train_autoencoder runs only on an MI355X through libtad_hip.so (device=%r)" % (device,))
+    tr = VAETrainer(ae, data_dict, batch_size=batch_size, lr=lr, weight_decay=weight_decay, dtype=dtype,
+                    process_group=process_group, dev=dev)
+    eng = tr.eng
+    d = eng.device
+    T, L = tr.T, eng.lat
+
+    def draw(n):
+        # reference order: the CPU generator when the reference itself runs on CPU; randn_like on the device otherwise
+        if noise_source == "reference":
+            return torch.randn(n, T, L)
+        return torch.randn(n, T, L, device=d)
+
+    beta = max_beta
+    patience, lambd = 0, 0.7
+    best_val, best_train = float("inf"), float("inf")
+    best_flat = eng.fp.flat.clone()
+    history = {"train": [], "val": []}
+    bar = None
+    if progress:
+        from rich.progress import Progress
+        bar = Progress()
+        bar.start()
+        task = bar.add_task("[red]Training", total=n_epochs)
+    for epoch in range(n_epochs):
+        idx = random.sample(tr.all_indices, batch_size)
+        train_loss = tr.train_step(beta, idx=idx, eps=draw(batch_size))
+        if select == "train" and train_loss < best_train:
+            best_train = train_loss
+            best_flat.copy_(eng.fp.flat)
+        val_loss = tr.eval_loss(beta, eps=draw(tr.Nv))
+        if val_loss < best_val:
+            best_val = val_loss
+            if select == "val":
+                best_flat.copy_(eng.fp.flat)
+            patience = 0
+        else:
+            patience += 1
+            if patience == 10 and beta > min_beta:
+                beta *= lambd
+                patience = 0
+        history["train"].append(train_loss)
+        history["val"].append(val_loss)
+        if bar is not None:
+            bar.update(task, advance=1)
+    if bar is not None:
+        bar.stop()
+    eng.fp.flat.copy_(best_flat)
+    eng.fp.version += 1
+    ae.eval()
+    output, latent = tr.full_forward(eps=draw(N))
+    return ae, latent.detach(), output, history
+
+
+def train_autoencoder(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size, threshold,
+                      min_beta, max_beta, emb_dim, time_dim, lat_dim, device, data_dict, *, dtype="fp32",
+                      process_group=None, noise_source="device", progress=False):
+    """reference VAE.py:261-404: weights selected by lowest validation loss.  ``real_df``,
+    ``channels`` and ``threshold`` are accepted and ignored like the reference.  Returns
+    (ae, latent (sampled z of the training set under the best weights), output dict, history)."""
+    return _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size, threshold,
+                  min_beta, max_beta, emb_dim, time_dim, lat_dim, device, data_dict, "val", dtype, process_group,
+                  noise_source, progress)
+
+
+def train_autoencoder_best_train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size,
+                                 threshold, min_beta, max_beta, emb_dim, time_dim, lat_dim, device, data_dict, *,
+                                 dtype="fp32", process_group=None, noise_source="device", progress=False):
+    """reference VAE.py:416-568: weights selected by lowest *training* loss."""
+    return _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size, threshold,
+                  min_beta, max_beta, emb_dim, time_dim, lat_dim, device, data_dict, "train", dtype, process_group,
+                  noise_source, progress)

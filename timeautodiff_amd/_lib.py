@@ -1,0 +1,89 @@
+"""ctypes binding of libtad_hip.so (the C ABI declared in include/tad_hip.h).
+
+The library is the only compute path of this package: if it is missing the loader
+raises, there is no fallback.  Build it with ``python __graft_entry__.py`` (or
+``make -C timeautodiff_amd/csrc``)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtad_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+CELL_LSTM, CELL_GRU = 0, 1
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i = C.c_int
+_f = C.c_float
+
+
+class RnnDir(C.Structure):
+    _fields_ = [("xproj", _p), ("ld_xproj", _i64), ("w_packed", _p), ("b_hh", _p), ("out", _p), ("ld_out", _i64),
+                ("stash", _p), ("reverse", C.c_int32), ("pad_", C.c_int32)]
+
+
+class RnnBwdDir(C.Structure):
+    _fields_ = [("dout", _p), ("ld_dout", _i64), ("stash", _p), ("out", _p), ("ld_out", _i64), ("w_packed_t", _p),
+                ("dgates", _p), ("dgates_h", _p), ("ld_dgates", _i64), ("reverse", C.c_int32), ("pad_", C.c_int32)]
+
+
+# name -> (restype, argtypes); must list every function declared in include/tad_hip.h
+PROTOTYPES = {
+    "tad_abi_version": (_i, []),
+    "tad_last_error": (C.c_char_p, []),
+    "tad_linear_fwd": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i, _p]),
+    "tad_linear_bwd_data": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
+    "tad_linear_bwd_weight": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
+    "tad_colsum": (_i, [_i64, _i64, _p, _i64, _p, _i64, _f, _p, _p, _p, _p]),
+    "tad_rnn_fwd": (_i, [_i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p]),
+    "tad_rnn_bwd": (_i, [_i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnBwdDir), _p]),
+    "tad_rnn_packed_bytes": (_i64, [_i, _i64, _i]),
+    "tad_rnn_pack_weights": (_i, [_i, _i64, _i, _p, _p, _p, _p]),
+    "tad_add_noise": (_i, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "tad_sampler_update": (_i, [_i64, _p, _p, _p, _f, _f, _f, _i, _p]),
+    "tad_mse_loss": (_i, [_i64, _p, _p, _f, _p, _p, _p]),
+    "tad_sincos_features": (_i, [_i64, _i, _p, _i64, _p, _i64, _p]),
+    "tad_embed_fwd": (_i, [_i64, _i, _i, _p, _i64, _p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _p, _i64, _p]),
+    "tad_embed_bwd": (_i, [_i64, _i, _i, _p, _i64, _p, _i64, _p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _p]),
+    "tad_posenc_fwd": (_i, [_i64, _i, _p, _i64, _f, _p, _p, _p, _p, _p, _i64, _p]),
+    "tad_silu_fwd": (_i, [_i64, _p, _p, _p]),
+    "tad_silu_bwd": (_i, [_i64, _p, _p, _p, _p]),
+    "tad_layernorm_fwd": (_i, [_i64, _i, _p, _i64, _p, _p, _f, _p, _i64, _p, _p]),
+    "tad_layernorm_bwd": (_i, [_i64, _i, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
+    "tad_gather_rows": (_i, [_i64, _i64, _p, _p, _p, _p]),
+    "tad_adam_step": (_i, [_i64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
+    "tad_vae_reparam_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _p]),
+    "tad_vae_reparam_bwd": (_i, [_i64, _p, _p, _p, _p, _f, _p, _p, _p]),
+    "tad_vae_heads_loss": (_i, [_i64, _i, _i, _i, C.POINTER(C.c_int32), _p, _i64, _p, _p, _i64, _f, _f, _f, _p, _p, _p]),
+    "tad_vae_prepare": (_i, [_i64, _p, _p, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class TadError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TadError(f"{LIB_PATH} not found: the HIP extension is not built "
+                           f"(run `python __graft_entry__.py` at the repository root); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load()
+        raise TadError(lib.tad_last_error().decode())

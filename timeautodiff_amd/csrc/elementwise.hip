@@ -1,0 +1,496 @@
+// Fused elementwise / reduction kernels of the TimeAutoDiff hot path (gfx950).
+// All of these are HBM-bound: one pass over their operands, coalesced along the
+// fastest dimension, wave-level reductions (64 lanes) followed by one atomic per wave
+// or workgroup for the scalar / per-column results.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+constexpr int MAX_DISC = 64;
+
+inline unsigned ew_grid(int64_t n, int per_thread = 1) {
+  int64_t g = cdiv64(n, (int64_t)EW_BLOCK * per_thread);
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// block-wide sum of one value per thread -> atomicAdd(out) once per block
+__device__ __forceinline__ void block_atomic_sum(float v, float* out) {
+  __shared__ float part[EW_BLOCK / 64];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w];
+    atomicAdd(out, s);
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+__global__ void add_noise_kernel(int64_t B, int64_t T, int64_t K, const float* __restrict__ x0,
+                                 const float* __restrict__ noise, const int32_t* __restrict__ i_idx,
+                                 const float* __restrict__ alphas, float* __restrict__ xn, float* __restrict__ i_f) {
+  const int64_t row = T * K, n = B * row;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / row;
+    const int i = i_idx[b];
+    const float a = alphas[i];
+    xn[e] = sqrtf(a) * x0[e] + sqrtf(1.f - a) * noise[e];
+    if (i_f) {
+      const int64_t w = e - b * row;
+      if (w < T) i_f[b * T + w] = (float)i;
+    }
+  }
+}
+
+__global__ void sampler_update_kernel(int64_t n, float* __restrict__ x, const float* __restrict__ pred,
+                                      const float* __restrict__ z, float c1, float c2, float c3, int last) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float p = pred[e];
+    // same operation order as the reference expression: c1 * (x - beta*pred/sqrt(1-alpha)) + sqrt(beta)*z
+    float v = __fadd_rn(__fmul_rn(c1, __fsub_rn(x[e], __fmul_rn(c2, p))), __fmul_rn(c3, z[e]));
+    if (last) v = __fmul_rn(c1, __fsub_rn(v, __fmul_rn(c2, p)));
+    x[e] = v;
+  }
+}
+
+__global__ void mse_loss_kernel(int64_t n, const float* __restrict__ pred, const float* __restrict__ target,
+                                float gscale, float* __restrict__ dpred, float* __restrict__ loss_sum) {
+  float acc = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float d = pred[e] - target[e];
+    acc += d * d;
+    if (dpred) dpred[e] = gscale * d;
+  }
+  if (loss_sum) block_atomic_sum(acc, loss_sum);
+}
+
+// out[r, j*8+k] = sin(2^k pi x[r,j]);  out[r, 8n + j*8+k] = cos(...)
+__global__ void sincos_kernel(int64_t rows, int nn, const float* __restrict__ x, int64_t ldx, float* __restrict__ out,
+                              int64_t ldo) {
+  const int64_t n = rows * nn * 8;
+  const float pi = 3.14159265358979323846f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / (nn * 8);
+    const int c = (int)(e - r * (nn * 8));
+    const int j = c >> 3, k = c & 7;
+    const float freq = __fmul_rn((float)(1 << k), pi);    // exact power-of-two scaling of float(pi)
+    const float ang = __fmul_rn(freq, x[r * ldx + j]);
+    float s, co;
+    sincosf(ang, &s, &co);
+    out[r * ldo + c] = s;
+    out[r * ldo + nn * 8 + c] = co;
+  }
+}
+
+struct DiscMeta {
+  int32_t off[MAX_DISC];
+  int32_t card[MAX_DISC];
+};
+
+__global__ void embed_fwd_kernel(int64_t rows, int nd, int E, const float* __restrict__ x, int64_t ldx,
+                                 const float* __restrict__ tables, DiscMeta m, float* __restrict__ out, int64_t ldo) {
+  const int64_t n = rows * nd * E;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / (nd * E);
+    const int c = (int)(e - r * (nd * E));
+    const int d = c / E, q = c - d * E;
+    int code = (int)x[r * ldx + d];
+    code = min(max(code, 0), m.card[d] - 1);
+    out[r * ldo + c] = tables[((int64_t)m.off[d] + code) * E + q];
+  }
+}
+
+// One workgroup = one discrete column and one slab of rows; the column's table gradient is
+// accumulated in LDS (ds_add_f32) and flushed with one global atomic per touched entry.
+__global__ void embed_bwd_lds_kernel(int64_t rows, int nd, int E, const float* __restrict__ x, int64_t ldx,
+                                     const float* __restrict__ dout, int64_t ldo, float* __restrict__ dtables,
+                                     DiscMeta m, int64_t rows_per_block) {
+  extern __shared__ float tab[];
+  const int d = blockIdx.y;
+  const int card = m.card[d];
+  for (int i = threadIdx.x; i < card * E; i += blockDim.x) tab[i] = 0.f;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  const int64_t n = (r1 - r0) * E;
+  for (int64_t e = threadIdx.x; e < n; e += blockDim.x) {
+    const int64_t r = r0 + e / E;
+    const int q = (int)(e % E);
+    int code = (int)x[r * ldx + d];
+    code = min(max(code, 0), card - 1);
+    atomicAdd(&tab[code * E + q], dout[r * ldo + (int64_t)d * E + q]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < card * E; i += blockDim.x) {
+    const float v = tab[i];
+    if (v != 0.f) atomicAdd(&dtables[(int64_t)m.off[d] * E + i], v);
+  }
+}
+
+__global__ void embed_bwd_direct_kernel(int64_t rows, int nd, int E, const float* __restrict__ x, int64_t ldx,
+                                        const float* __restrict__ dout, int64_t ldo, float* __restrict__ dtables,
+                                        DiscMeta m) {
+  const int64_t n = rows * nd * E;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / (nd * E);
+    const int c = (int)(e - r * (nd * E));
+    const int d = c / E, q = c - d * E;
+    int code = (int)x[r * ldx + d];
+    code = min(max(code, 0), m.card[d] - 1);
+    atomicAdd(&dtables[((int64_t)m.off[d] + code) * E + q], dout[r * ldo + c]);
+  }
+}
+
+__global__ void posenc_kernel(int64_t rows, int H, const float* __restrict__ t, int64_t ts, float inv_max,
+                              const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
+                              const float* __restrict__ shift, float* __restrict__ out, int64_t ldo) {
+  const int L = H / 2;
+  const int64_t n = rows * H;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / H;
+    const int c = (int)(e - r * H);
+    const float tv = t[r * ts];
+    float v;
+    if (c < L) v = __fadd_rn(__fmul_rn(__fmul_rn(tv, inv_max), w[c]), b[c]);
+    else v = sinf(__fadd_rn(__fmul_rn(tv, scale[c - L]), shift[c - L]));
+    out[r * ldo + c] = v;
+  }
+}
+
+__global__ void silu_fwd_kernel(int64_t n, const float* __restrict__ z, float* __restrict__ a) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float v = z[e];
+    a[e] = v * sigmoid_acc(v);
+  }
+}
+
+__global__ void silu_bwd_kernel(int64_t n, const float* __restrict__ z, const float* __restrict__ da, float* __restrict__ dz) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float v = z[e], s = sigmoid_acc(v);
+    dz[e] = da[e] * s * (1.f + v * (1.f - s));
+  }
+}
+
+// one wave per row
+__global__ void layernorm_fwd_kernel(int64_t rows, int D, const float* __restrict__ x, int64_t ldx,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     float* __restrict__ y, int64_t ldy, float* __restrict__ mr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float* xr = x + r * ldx;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)D;
+    float v = 0.f;
+    for (int c = lane; c < D; c += 64) { const float dlt = xr[c] - mean; v += dlt * dlt; }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
+    for (int c = lane; c < D; c += 64) y[r * ldy + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    if (mr && lane == 0) { mr[2 * r] = mean; mr[2 * r + 1] = rstd; }
+  }
+}
+
+template <int NC>
+__global__ void layernorm_bwd_kernel(int64_t rows, int D, const float* __restrict__ dy, int64_t lddy,
+                                     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                     const float* __restrict__ mr, float* __restrict__ dx, int64_t lddx,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float dg[NC], db[NC], gm[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    dg[i] = 0.f; db[i] = 0.f;
+    const int c = lane + 64 * i;
+    gm[i] = c < D ? gamma[c] : 0.f;
+  }
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float mean = mr[2 * r], rstd = mr[2 * r + 1];
+    float xh[NC], dxh[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      xh[i] = 0.f; dxh[i] = 0.f;
+      if (c < D) {
+        const float g = dy[r * lddy + c];
+        xh[i] = (x[r * ldx + c] - mean) * rstd;
+        dxh[i] = g * gm[i];
+        dg[i] += g * xh[i];
+        db[i] += g;
+        s1 += dxh[i];
+        s2 += dxh[i] * xh[i];
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) dx[r * lddx + c] = rstd * (dxh[i] - m1 - xh[i] * m2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) {
+      atomicAdd(&dgamma[c], dg[i]);
+      atomicAdd(&dbeta[c], db[i]);
+    }
+  }
+}
+
+__global__ void gather_rows_kernel(int64_t rows, int64_t len, const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                   float* __restrict__ out) {
+  const int64_t n = rows * len;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / len, c = e - r * len;
+    out[e] = src[idx[r] * len + c];
+  }
+}
+
+__global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float b1, float b2, float eps, float wd, float step_size,
+                            float inv_sqrt_bc2) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float pe = p[e];
+    float ge = g[e];
+    if (wd != 0.f) ge += wd * pe;
+    float me = m[e], ve = v[e];
+    me += (ge - me) * (1.f - b1);
+    ve = ve * b2 + (1.f - b2) * ge * ge;
+    m[e] = me; v[e] = ve;
+    const float denom = sqrtf(ve) * inv_sqrt_bc2 + eps;
+    p[e] = pe - step_size * (me / denom);
+  }
+}
+
+// out_sum[c] += sum_r dY[r,c]; out_wsum[c] += sum_r dY[r,c] * scale[r]
+__global__ void colsum_kernel(int64_t M, int64_t N, const float* __restrict__ dY, int64_t ldy,
+                              const float* __restrict__ rs, int64_t rs_stride, float mul, float* __restrict__ o1,
+                              float* __restrict__ o2, float* __restrict__ ow, int64_t rows_per_block) {
+  __shared__ float p1[4][64], p2[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(M, r0 + rows_per_block);
+  float a = 0.f, w = 0.f;
+  if (c < N) {
+    for (int64_t r = r0 + ty; r < r1; r += 4) {
+      const float v = dY[r * ldy + c];
+      a += v;
+      if (ow) w += v * rs[r * rs_stride];
+    }
+  }
+  p1[ty][tx] = a; p2[ty][tx] = w;
+  __syncthreads();
+  if (ty == 0 && c < N) {
+    a = p1[0][tx] + p1[1][tx] + p1[2][tx] + p1[3][tx];
+    w = p2[0][tx] + p2[1][tx] + p2[2][tx] + p2[3][tx];
+    if (o1) atomicAdd(&o1[c], a);
+    if (o2) atomicAdd(&o2[c], a);
+    if (ow) atomicAdd(&ow[c], w * mul);
+  }
+}
+
+}  // namespace
+
+#define EW_STREAM ((hipStream_t)stream)
+
+extern "C" int tad_add_noise(int64_t B, int64_t T, int64_t K, const float* x0, const float* noise, const int32_t* i_idx,
+                             const float* alphas, float* x_noisy, float* i_f, tad_stream_t stream) {
+  TAD_CHECK(B >= 0 && T > 0 && K > 0 && x0 && noise && i_idx && alphas && x_noisy, "tad_add_noise: bad arguments");
+  if (B == 0) return TAD_OK;
+  hipLaunchKernelGGL(add_noise_kernel, dim3(ew_grid(B * T * K)), dim3(EW_BLOCK), 0, EW_STREAM, B, T, K, x0, noise, i_idx,
+                     alphas, x_noisy, i_f);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_sampler_update(int64_t n, float* x, const float* pred, const float* z, float c1, float c2, float c3,
+                                  int last, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && x && pred && z, "tad_sampler_update: bad arguments");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(sampler_update_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, x, pred, z, c1, c2, c3, last);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_mse_loss(int64_t n, const float* pred, const float* target, float grad_scale, float* dpred,
+                            float* loss_sum, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && pred && target, "tad_mse_loss: bad arguments");
+  if (n == 0) return TAD_OK;
+  unsigned g = ew_grid(n, 4);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(g), dim3(EW_BLOCK), 0, EW_STREAM, n, pred, target, grad_scale, dpred, loss_sum);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_sincos_features(int64_t rows, int n_nums, const float* x, int64_t ldx, float* out, int64_t ldo,
+                                   tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && n_nums > 0 && x && out && ldx >= n_nums && ldo >= 16 * n_nums, "tad_sincos_features: bad arguments");
+  if (rows == 0) return TAD_OK;
+  hipLaunchKernelGGL(sincos_kernel, dim3(ew_grid(rows * n_nums * 8)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_nums, x, ldx, out, ldo);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+static int fill_meta(DiscMeta& m, int n_disc, const int32_t* tab_off, const int32_t* cards, const char* who) {
+  if (n_disc <= 0 || n_disc > MAX_DISC || !tab_off || !cards) {
+    tad_set_error("%s: n_disc=%d out of range (1..%d) or null metadata", who, n_disc, MAX_DISC);
+    return TAD_ERR_INVALID;
+  }
+  for (int d = 0; d < n_disc; ++d) {
+    if (cards[d] <= 0 || tab_off[d] < 0) {
+      tad_set_error("%s: bad table metadata for column %d", who, d);
+      return TAD_ERR_INVALID;
+    }
+    m.off[d] = tab_off[d];
+    m.card[d] = cards[d];
+  }
+  return TAD_OK;
+}
+
+extern "C" int tad_embed_fwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* tables,
+                             const int32_t* tab_off, const int32_t* cards, float* out, int64_t ldo, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && E > 0 && x && tables && out && ldx >= n_disc && ldo >= (int64_t)n_disc * E, "tad_embed_fwd: bad arguments");
+  DiscMeta m{};
+  if (int rc = fill_meta(m, n_disc, tab_off, cards, "tad_embed_fwd")) return rc;
+  if (rows == 0) return TAD_OK;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(ew_grid(rows * n_disc * E)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_disc, E, x, ldx,
+                     tables, m, out, ldo);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_embed_bwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* dout, int64_t ldo,
+                             float* dtables, const int32_t* tab_off, const int32_t* cards, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && E > 0 && x && dout && dtables && ldx >= n_disc && ldo >= (int64_t)n_disc * E, "tad_embed_bwd: bad arguments");
+  DiscMeta m{};
+  if (int rc = fill_meta(m, n_disc, tab_off, cards, "tad_embed_bwd")) return rc;
+  if (rows == 0) return TAD_OK;
+  int maxcard = 0;
+  for (int d = 0; d < n_disc; ++d) maxcard = cards[d] > maxcard ? cards[d] : maxcard;
+  const size_t lds = (size_t)maxcard * E * sizeof(float);
+  if (lds <= 48 * 1024) {
+    int64_t nb = cdiv64(rows, 256);
+    if (nb > 512) nb = 512;
+    const int64_t rpb = cdiv64(rows, nb);
+    nb = cdiv64(rows, rpb);
+    hipLaunchKernelGGL(embed_bwd_lds_kernel, dim3((unsigned)nb, (unsigned)n_disc), dim3(EW_BLOCK), lds, EW_STREAM, rows, n_disc, E,
+                       x, ldx, dout, ldo, dtables, m, rpb);
+  } else {
+    hipLaunchKernelGGL(embed_bwd_direct_kernel, dim3(ew_grid(rows * n_disc * E)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_disc, E, x,
+                       ldx, dout, ldo, dtables, m);
+  }
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_posenc_fwd(int64_t rows, int H, const float* t, int64_t t_stride, float inv_max, const float* w,
+                              const float* b, const float* scale, const float* shift, float* out, int64_t ldo,
+                              tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && H >= 2 && t && w && b && scale && shift && out && ldo >= H, "tad_posenc_fwd: bad arguments");
+  if (rows == 0) return TAD_OK;
+  hipLaunchKernelGGL(posenc_kernel, dim3(ew_grid(rows * H)), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max, w, b,
+                     scale, shift, out, ldo);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_silu_fwd(int64_t n, const float* z, float* a, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && z && a, "tad_silu_fwd: bad arguments");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, z, a);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_silu_bwd(int64_t n, const float* z, const float* da, float* dz, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && z && da && dz, "tad_silu_bwd: bad arguments");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, z, da, dz);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_layernorm_fwd(int64_t rows, int D, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                 float eps, float* y, int64_t ldy, float* mean_rstd, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && D > 0 && x && gamma && beta && y && ldx >= D && ldy >= D, "tad_layernorm_fwd: bad arguments");
+  if (rows == 0) return TAD_OK;
+  int64_t g = cdiv64(rows, EW_BLOCK / 64);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)g), dim3(EW_BLOCK), 0, EW_STREAM, rows, D, x, ldx, gamma, beta, eps, y,
+                     ldy, mean_rstd);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_layernorm_bwd(int64_t rows, int D, const float* dy, int64_t lddy, const float* x, int64_t ldx,
+                                 const float* gamma, const float* mean_rstd, float* dx, int64_t lddx, float* dgamma,
+                                 float* dbeta, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && D > 0 && D <= 2048 && dy && x && gamma && mean_rstd && dx && dgamma && dbeta, "tad_layernorm_bwd: bad arguments (D <= 2048)");
+  TAD_CHECK(lddy >= D && ldx >= D && lddx >= D, "tad_layernorm_bwd: bad leading dimension");
+  if (rows == 0) return TAD_OK;
+  int64_t g = cdiv64(rows, EW_BLOCK / 64);
+  if (g > 512) g = 512;
+  const int nc = (int)cdiv64(D, 64);
+#define LN_BWD(NC) hipLaunchKernelGGL(layernorm_bwd_kernel<NC>, dim3((unsigned)g), dim3(EW_BLOCK), 0, EW_STREAM, rows, D, dy, lddy, x, ldx, gamma, mean_rstd, dx, lddx, dgamma, dbeta)
+  if (nc <= 2) LN_BWD(2);
+  else if (nc <= 8) LN_BWD(8);
+  else if (nc <= 16) LN_BWD(16);
+  else LN_BWD(32);
+#undef LN_BWD
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_gather_rows(int64_t rows, int64_t row_len, const float* src, const int64_t* idx, float* out,
+                               tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && row_len > 0 && src && idx && out, "tad_gather_rows: bad arguments");
+  if (rows == 0) return TAD_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(rows * row_len)), dim3(EW_BLOCK), 0, EW_STREAM, rows, row_len, src, idx, out);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_adam_step(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && p && g && m && v && step >= 1, "tad_adam_step: bad arguments");
+  if (n == 0) return TAD_OK;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, p, g, m, v, beta1, beta2, eps, weight_decay,
+                     step_size, inv_sqrt_bc2);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_colsum(int64_t M, int64_t N, const float* dY, int64_t ldy, const float* row_scale,
+                          int64_t row_scale_stride, float scale_mul, float* out_sum, float* out_sum2, float* out_wsum,
+                          tad_stream_t stream) {
+  TAD_CHECK(M >= 0 && N > 0 && dY && ldy >= N, "tad_colsum: bad arguments");
+  TAD_CHECK(!out_wsum || row_scale, "tad_colsum: out_wsum needs row_scale");
+  if (M == 0) return TAD_OK;
+  const int64_t ctiles = cdiv64(N, 64);
+  int64_t slabs = cdiv64(1024, ctiles);
+  if (slabs > cdiv64(M, 64)) slabs = cdiv64(M, 64);
+  if (slabs < 1) slabs = 1;
+  const int64_t rpb = cdiv64(M, slabs);
+  slabs = cdiv64(M, rpb);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ctiles, (unsigned)slabs), dim3(EW_BLOCK), 0, EW_STREAM, M, N, dY, ldy, row_scale,
+                     row_scale_stride, scale_mul, out_sum, out_sum2, out_wsum, rpb);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}

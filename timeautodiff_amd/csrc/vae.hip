@@ -1,0 +1,175 @@
+// VAE-specific fused kernels (gfx950): reparametrisation + KLD, and the decoder-head
+// epilogue (mask injection, sigmoid) fused with the mixed BCE / CE / MSE loss and its
+// gradient.  HBM-bound, one pass over the head pre-activations.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int VB = 256;
+constexpr int MAX_CATS = 64;
+
+__device__ __forceinline__ void block_sum_to(float v, float* out) {
+  __shared__ float part[VB / 64];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) part[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < VB / 64; ++w) s += part[w];
+    if (s != 0.f) atomicAdd(out, s);
+  }
+}
+
+__global__ void reparam_fwd_kernel(int64_t n, const float* __restrict__ mu, const float* __restrict__ lv,
+                                   const float* __restrict__ eps, float* __restrict__ z, float* __restrict__ kld_sum) {
+  float acc = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float m = mu[e], l = lv[e];
+    z[e] = m + eps[e] * expf(0.5f * l);
+    acc += 1.f + l - m * m - expf(l);
+  }
+  if (kld_sum) block_sum_to(acc, kld_sum);
+}
+
+__global__ void reparam_bwd_kernel(int64_t n, const float* __restrict__ dz, const float* __restrict__ mu,
+                                   const float* __restrict__ lv, const float* __restrict__ eps, float ks,
+                                   float* __restrict__ dmu, float* __restrict__ dlv) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float g = dz[e], l = lv[e];
+    dmu[e] = g + ks * mu[e];
+    dlv[e] = g * eps[e] * 0.5f * expf(0.5f * l) - 0.5f * ks * (1.f - expf(l));
+  }
+}
+
+struct HeadMeta {
+  int32_t card[MAX_CATS];
+};
+
+// one thread per row
+__global__ void heads_loss_kernel(int64_t rows, int nb, int nc, int nn, HeadMeta hm, float* __restrict__ heads, int64_t ldh,
+                                  const float* __restrict__ mask, const float* __restrict__ target, int64_t ldf,
+                                  float s_bce, float s_ce, float s_mse, float* __restrict__ dheads,
+                                  float* __restrict__ parts) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = r < rows;
+  float bce = 0.f, mse = 0.f;
+  float* h = heads + (live ? r : 0) * ldh;
+  float* dh = dheads ? dheads + (live ? r : 0) * ldh : nullptr;
+  const float* mk = mask + (live ? r : 0) * ldf;
+  const float* tg = target + (live ? r : 0) * ldf;
+  int col = 0;
+  if (live) {
+    for (int j = 0; j < nb; ++j, ++col) {
+      const float x = h[col] + (mk[j] == 0.f ? -100.f : 0.f);
+      const float y = tg[j];
+      h[col] = x;
+      bce += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+      if (dh) dh[col] = (sigmoid_acc(x) - y) * s_bce;
+    }
+  } else {
+    col += nb;
+  }
+  for (int j = 0; j < nc; ++j) {
+    const int card = hm.card[j];
+    float ce = 0.f;
+    if (live) {
+      h[col] += (mk[nb + j] == 0.f ? 100.f : 0.f);
+      float mx = h[col];
+      for (int q = 1; q < card; ++q) mx = fmaxf(mx, h[col + q]);
+      float se = 0.f;
+      for (int q = 0; q < card; ++q) se += expf(h[col + q] - mx);
+      const float lse = mx + logf(se);
+      int t = (int)tg[nb + j];
+      t = min(max(t, 0), card - 1);
+      ce = lse - h[col + t];
+      if (dh) {
+        for (int q = 0; q < card; ++q) dh[col + q] = (expf(h[col + q] - lse) - (q == t ? 1.f : 0.f)) * s_ce;
+      }
+    }
+    col += card;
+    if (parts) block_sum_to(ce, parts + 2 + j);
+  }
+  if (live) {
+    for (int j = 0; j < nn; ++j, ++col) {
+      const float s = sigmoid_acc(h[col]);
+      const float m = mk[nb + nc + j];
+      const float o = s * m;
+      h[col] = o;
+      const float d = o - tg[nb + nc + j];
+      mse += d * d;
+      if (dh) dh[col] = s_mse * d * m * s * (1.f - s);
+    }
+  }
+  if (parts) {
+    block_sum_to(bce, parts + 0);
+    block_sum_to(mse, parts + 1);
+  }
+}
+
+__global__ void prepare_kernel(int64_t n, const float* __restrict__ a, const float* __restrict__ b,
+                               const float* __restrict__ mask, float* __restrict__ inp, float* __restrict__ target) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float v = a[e] + (b ? b[e] : 0.f);
+    if (inp) inp[e] = v;
+    if (target) target[e] = v * mask[e];
+  }
+}
+
+inline unsigned vgrid(int64_t n) {
+  int64_t g = cdiv64(n, VB);
+  if (g > 2048) g = 2048;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int tad_vae_reparam_fwd(int64_t n, const float* mu, const float* lv, const float* eps, float* z, float* kld_sum,
+                                   tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && mu && lv && eps && z, "tad_vae_reparam_fwd: bad arguments");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(vgrid(n)), dim3(VB), 0, (hipStream_t)stream, n, mu, lv, eps, z, kld_sum);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_vae_reparam_bwd(int64_t n, const float* dz, const float* mu, const float* lv, const float* eps,
+                                   float kld_scale, float* dmu, float* dlv, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && dz && mu && lv && eps && dmu && dlv, "tad_vae_reparam_bwd: bad arguments");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(vgrid(n)), dim3(VB), 0, (hipStream_t)stream, n, dz, mu, lv, eps, kld_scale, dmu, dlv);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_vae_heads_loss(int64_t rows, int nb, int nc, int nn, const int32_t* cards, float* heads, int64_t ldh,
+                                  const float* mask, const float* target, int64_t ldf, float scale_bce, float scale_ce,
+                                  float scale_mse, float* dheads, float* loss_parts, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && nb >= 0 && nc >= 0 && nn >= 0 && nc <= MAX_CATS && heads && mask && target, "tad_vae_heads_loss: bad arguments");
+  TAD_CHECK(nc == 0 || cards, "tad_vae_heads_loss: cards missing");
+  HeadMeta hm{};
+  int64_t nh = nb + nn;
+  for (int j = 0; j < nc; ++j) {
+    TAD_CHECK(cards[j] > 0, "tad_vae_heads_loss: bad cardinality");
+    hm.card[j] = cards[j];
+    nh += cards[j];
+  }
+  TAD_CHECK(ldh >= nh && ldf >= nb + nc + nn, "tad_vae_heads_loss: bad leading dimension");
+  if (rows == 0) return TAD_OK;
+  hipLaunchKernelGGL(heads_loss_kernel, dim3((unsigned)cdiv64(rows, VB)), dim3(VB), 0, (hipStream_t)stream, rows, nb, nc, nn, hm,
+                     heads, ldh, mask, target, ldf, scale_bce, scale_ce, scale_mse, dheads, loss_parts);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_vae_prepare(int64_t n, const float* resp, const float* cond, const float* mask, float* inp, float* target,
+                               tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && resp && (!target || mask), "tad_vae_prepare: bad arguments");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(prepare_kernel, dim3(vgrid(n)), dim3(VB), 0, (hipStream_t)stream, n, resp, cond, mask, inp, target);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}

@@ -1,0 +1,693 @@
+"""Host-side orchestration of the HIP kernels: flat parameter storage, workspaces and
+the forward/backward launch sequences of the denoiser (BiRNN_score) and the VAE
+(DeapStack).  All arithmetic happens in libtad_hip.so; torch only owns the memory."""
+import math
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .ops import ACT_RELU, BF16, CELL_GRU, CELL_LSTM, F32
+
+ALIGN = 64  # floats (256 B)
+
+
+def prec_of(dtype):
+    """'fp32'/torch.float32 -> F32 (exact fp32 MFMA), 'bf16'/torch.bfloat16 -> BF16 operands."""
+    if dtype in (F32, "fp32", "f32", torch.float32, None):
+        return F32
+    if dtype in (BF16, "bf16", torch.bfloat16):
+        return BF16
+    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'fp32' or 'bf16')")
+
+
+class FlatParams:
+    """All parameters of a module in ONE contiguous fp32 device buffer (plus same-shaped
+    gradient and Adam moment buffers).  The module's nn.Parameters are re-pointed to
+    views of it, so state_dict()/load_state_dict() keep working with the reference's key
+    names, while the kernels, the fused Adam and the gradient all-reduce address flat
+    ranges.  ``layout`` is a list of (name, glue) in memory order; glue=True places the
+    tensor directly after the previous one (groups the kernels read as one matrix).
+    Names listed in ``inactive`` (parameters the forward never uses, which therefore
+    never get a gradient in the reference) are stored after the active range and are
+    excluded from the optimizer and the all-reduce."""
+
+    def __init__(self, module, layout, inactive, device):
+        params = dict(module.named_parameters())
+        names = [n for n, _ in layout] + list(inactive)
+        assert sorted(names) == sorted(params), (set(names) ^ set(params))
+        self.offsets = {}
+        off = 0
+        for name, glue in layout:
+            if not glue:
+                off = (off + ALIGN - 1) // ALIGN * ALIGN
+            self.offsets[name] = off
+            off += params[name].numel()
+        self.n_active = off
+        off = (off + ALIGN - 1) // ALIGN * ALIGN
+        for name in inactive:
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
+            self.offsets[name] = off
+            off += params[name].numel()
+        self.total = off
+        self.device = device
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.gflat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.m = torch.zeros(self.n_active, dtype=torch.float32, device=device)
+        self.v = torch.zeros(self.n_active, dtype=torch.float32, device=device)
+        self.step = 0
+        self.shapes = {n: tuple(p.shape) for n, p in params.items()}
+        self.version = 0          # bumped whenever parameter values change
+        for name, p in params.items():
+            view = self.p(name)
+            view.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = view
+            p.grad = self.g(name) if self.offsets[name] < self.n_active else None
+        self._params = params
+
+    def owns(self, module):
+        """True while the module's parameters still alias this buffer (a .to()/.cuda()
+        or a manual re-assignment breaks the aliasing)."""
+        for name, p in module.named_parameters():
+            if p.data_ptr() != self.flat.data_ptr() + 4 * self.offsets[name]:
+                return False
+        return True
+
+    def _view(self, buf, name, n=None, shape=None):
+        off = self.offsets[name]
+        if n is None:
+            shape = self.shapes[name]
+            n = math.prod(shape)
+        return buf[off:off + n].view(shape)
+
+    def p(self, name):
+        return self._view(self.flat, name)
+
+    def g(self, name):
+        return self._view(self.gflat, name)
+
+    def pgroup(self, first, rows, cols):
+        """A [rows, cols] matrix view starting at tensor ``first`` (a glued group)."""
+        return self._view(self.flat, first, rows * cols, (rows, cols))
+
+    def ggroup(self, first, rows, cols):
+        return self._view(self.gflat, first, rows * cols, (rows, cols))
+
+    def zero_grad(self):
+        self.gflat[:self.n_active].zero_()
+
+    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.step += 1
+        ops.adam_step(self.flat[:self.n_active], self.gflat[:self.n_active], self.m, self.v, lr, betas[0], betas[1], eps,
+                      weight_decay, self.step)
+        self.version += 1
+
+
+class Workspace:
+    """Named device buffers, allocated on first use and reused while the shape is stable."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, name, shape, dtype=torch.float32, zero=False):
+        shape = tuple(int(s) for s in shape)
+        t = self.bufs.get(name)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.bufs[name] = t
+        if zero:
+            t.zero_()
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+# ---------------------------------------------------------------------------
+class RnnStack:
+    """Multi-layer LSTM/GRU with ``ndir`` directions ("bidir": every layer reads the
+    concatenated output of all directions of the layer below, directions run
+    forward/reverse in time) or independent heads ("heads": head d of layer l reads head
+    d of layer l-1, all run forward in time; layer 0 shares the input)."""
+
+    def __init__(self, fp: FlatParams, cell, H, in_dim, num_layers, dir_names, mode, prec):
+        self.fp, self.cell, self.H, self.in_dim, self.L, self.mode, self.prec = fp, cell, H, in_dim, num_layers, mode, prec
+        self.G = 4 if cell == CELL_LSTM else 3
+        self.S = 5 if cell == CELL_LSTM else 4
+        self.dir_names = dir_names              # list of (prefix, suffix_format)
+        self.ndir = len(dir_names)
+        self.rev = [False, True] if mode == "bidir" else [False] * self.ndir
+        nbytes = ops.rnn_packed_bytes(prec, H, self.G)
+        assert nbytes > 0
+        self.packed_f = [[torch.empty(nbytes, dtype=torch.uint8, device=fp.device) for _ in range(self.ndir)]
+                         for _ in range(num_layers)]
+        self.packed_b = [[torch.empty(nbytes, dtype=torch.uint8, device=fp.device) for _ in range(self.ndir)]
+                         for _ in range(num_layers)]
+        self._ver_f = self._ver_b = -1
+
+    def name(self, kind, layer, d):
+        prefix, sfx = self.dir_names[d]
+        return f"{prefix}{kind}{sfx.format(l=layer)}"
+
+    @staticmethod
+    def layout(dir_names, num_layers):
+        out = []
+        for kind in ("weight_ih", "bias_ih", "bias_hh", "weight_hh"):
+            for layer in range(num_layers):
+                for d, (prefix, sfx) in enumerate(dir_names):
+                    out.append((f"{prefix}{kind}{sfx.format(l=layer)}", d > 0))
+        return out
+
+    def in_l(self, layer):
+        if layer == 0:
+            return self.in_dim
+        return self.ndir * self.H if self.mode == "bidir" else self.H
+
+    def pack(self, need_bwd=True):
+        """Refresh the packed W_hh images if the parameters changed since the last pack."""
+        v = self.fp.version
+        do_f = self._ver_f != v
+        do_b = need_bwd and self._ver_b != v
+        if not (do_f or do_b):
+            return
+        for layer in range(self.L):
+            for d in range(self.ndir):
+                ops.rnn_pack_weights(self.prec, self.H, self.G, self.fp.p(self.name("weight_hh", layer, d)),
+                                     self.packed_f[layer][d] if do_f else None, self.packed_b[layer][d] if do_b else None)
+        if do_f:
+            self._ver_f = v
+        if do_b:
+            self._ver_b = v
+
+    def pack_fwd_only(self):
+        self.pack(need_bwd=False)
+
+    def forward(self, x, B, T, ws: Workspace, tag, train):
+        fp, H, G, nd, prec = self.fp, self.H, self.G, self.ndir, self.prec
+        BT = B * T
+        GH = G * H
+        self._in = x
+        self._B, self._T = B, T
+        inp = x
+        for layer in range(self.L):
+            xproj = ws.get(f"{tag}.xproj{layer}", (BT, nd * GH))
+            shared = self.mode == "bidir" or layer == 0
+            if shared:
+                w = fp.pgroup(self.name("weight_ih", layer, 0), nd * GH, self.in_l(layer))
+                b1 = fp.pgroup(self.name("bias_ih", layer, 0), 1, nd * GH)
+                b2 = fp.pgroup(self.name("bias_hh", layer, 0), 1, nd * GH) if self.cell == CELL_LSTM else None
+                ops.linear_fwd(prec, inp, w, b1, xproj, bias2=b2)
+            else:
+                for d in range(nd):
+                    b2 = fp.p(self.name("bias_hh", layer, d)) if self.cell == CELL_LSTM else None
+                    ops.linear_fwd(prec, inp[:, d * H:(d + 1) * H], fp.p(self.name("weight_ih", layer, d)),
+                                   fp.p(self.name("bias_ih", layer, d)), xproj[:, d * GH:(d + 1) * GH], bias2=b2)
+            out = ws.get(f"{tag}.out{layer}", (BT, nd * H))
+            stash = ws.get(f"{tag}.stash{layer}", (nd, BT, self.S * H)) if train else None
+            dirs = []
+            for d in range(nd):
+                dirs.append(dict(xproj=xproj[:, d * GH:(d + 1) * GH], w_packed=self.packed_f[layer][d],
+                                 b_hh=fp.p(self.name("bias_hh", layer, d)) if self.cell == CELL_GRU else None,
+                                 out=out[:, d * H:(d + 1) * H], stash=stash[d] if train else None, reverse=self.rev[d]))
+            ops.rnn_fwd(self.cell, prec, B, T, H, dirs)
+            inp = out
+        return inp
+
+    def backward(self, dout, ws: Workspace, tag, need_dx, relu_of=None):
+        fp, H, G, nd, prec = self.fp, self.H, self.G, self.ndir, self.prec
+        B, T = self._B, self._T
+        BT = B * T
+        GH = G * H
+        for layer in range(self.L - 1, -1, -1):
+            out = ws.get(f"{tag}.out{layer}", (BT, nd * H))
+            stash = ws.get(f"{tag}.stash{layer}", (nd, BT, self.S * H))
+            inp = self._in if layer == 0 else ws.get(f"{tag}.out{layer - 1}", (BT, nd * H))
+            dg = ws.get(f"{tag}.dg{layer}", (BT, nd * GH))
+            dgh = ws.get(f"{tag}.dgh{layer}", (BT, nd * GH)) if self.cell == CELL_GRU else None
+            dirs = []
+            for d in range(nd):
+                dirs.append(dict(dout=dout[:, d * H:(d + 1) * H], stash=stash[d], out=out[:, d * H:(d + 1) * H],
+                                 w_packed_t=self.packed_b[layer][d], dgates=dg[:, d * GH:(d + 1) * GH],
+                                 dgates_h=dgh[:, d * GH:(d + 1) * GH] if dgh is not None else None, reverse=self.rev[d]))
+            ops.rnn_bwd(self.cell, prec, B, T, H, dirs)
+            shared = self.mode == "bidir" or layer == 0
+            in_l = self.in_l(layer)
+            # input-side weights and biases
+            if shared:
+                ops.linear_bwd_weight(prec, dg, inp, fp.ggroup(self.name("weight_ih", layer, 0), nd * GH, in_l))
+            else:
+                for d in range(nd):
+                    ops.linear_bwd_weight(prec, dg[:, d * GH:(d + 1) * GH], inp[:, d * H:(d + 1) * H],
+                                          fp.g(self.name("weight_ih", layer, d)))
+            gb_ih = fp.ggroup(self.name("bias_ih", layer, 0), 1, nd * GH)
+            gb_hh = fp.ggroup(self.name("bias_hh", layer, 0), 1, nd * GH)
+            if self.cell == CELL_LSTM:
+                ops.colsum(dg, out_sum=gb_ih, out_sum2=gb_hh)
+            else:
+                ops.colsum(dg, out_sum=gb_ih)
+                ops.colsum(dgh, out_sum=gb_hh)
+            # recurrent weights: dW_hh += dgates^T h_{t-1}
+            src = dgh if self.cell == CELL_GRU else dg
+            for d in range(nd):
+                ops.linear_bwd_weight(prec, src[:, d * GH:(d + 1) * GH], out[:, d * H:(d + 1) * H],
+                                      fp.g(self.name("weight_hh", layer, d)), T=T, tshift=(1 if self.rev[d] else -1))
+            # gradient wrt the layer input
+            if layer > 0 or need_dx:
+                dx = ws.get(f"{tag}.dx{layer}", (BT, in_l))
+                ro = relu_of if layer == 0 else None
+                if shared:
+                    ops.linear_bwd_data(prec, dg, fp.pgroup(self.name("weight_ih", layer, 0), nd * GH, in_l), dx, relu_of=ro)
+                else:
+                    for d in range(nd):
+                        ops.linear_bwd_data(prec, dg[:, d * GH:(d + 1) * GH], fp.p(self.name("weight_ih", layer, d)),
+                                            dx[:, d * H:(d + 1) * H])
+                dout = dx
+            else:
+                dout = None
+        return dout
+
+
+# ---------------------------------------------------------------------------
+class EmbBlock:
+    """Embedding_data: per-column embedding lookups | sin/cos features -> mlp_nums, then mlp_output."""
+
+    def __init__(self, fp: FlatParams, prefix, n_bins, n_cats, n_nums, cards, E, prec):
+        self.fp, self.prefix, self.E, self.prec = fp, prefix, E, prec
+        self.nd = n_bins + n_cats
+        self.nn = n_nums
+        self.cards = [2] * n_bins + list(cards)[:n_cats]
+        self.tab_off = [0]
+        for c in self.cards[:-1]:
+            self.tab_off.append(self.tab_off[-1] + c)
+        self.cat_dim = self.nd * E + 16 * n_nums
+
+    @staticmethod
+    def layout(prefix, n_disc, n_nums):
+        out = [(f"{prefix}embeddings_list.{j}.weight", j > 0) for j in range(n_disc)]
+        if n_nums:
+            out += [(f"{prefix}mlp_nums.0.weight", False), (f"{prefix}mlp_nums.0.bias", False),
+                    (f"{prefix}mlp_nums.2.weight", False), (f"{prefix}mlp_nums.2.bias", False)]
+        out += [(f"{prefix}mlp_output.0.weight", False), (f"{prefix}mlp_output.0.bias", False),
+                (f"{prefix}mlp_output.2.weight", False), (f"{prefix}mlp_output.2.bias", False)]
+        return out
+
+    def forward(self, x, ws: Workspace, tag):
+        fp, pre, E, prec, nd, nn = self.fp, self.prefix, self.E, self.prec, self.nd, self.nn
+        rows = x.shape[0]
+        self._x = x
+        ecat = ws.get(f"{tag}.ecat", (rows, self.cat_dim))
+        if nd:
+            tables = fp.pgroup(f"{pre}embeddings_list.0.weight", sum(self.cards), E)
+            ops.embed_fwd(x[:, :nd], tables, self.tab_off, self.cards, E, ecat[:, :nd * E])
+        if nn:
+            feats = ws.get(f"{tag}.feats", (rows, 16 * nn))
+            z1 = ws.get(f"{tag}.z1", (rows, 16 * nn))
+            a1 = ws.get(f"{tag}.a1", (rows, 16 * nn))
+            ops.sincos_features(x[:, nd:nd + nn], feats)
+            ops.linear_fwd(prec, feats, fp.p(pre + "mlp_nums.0.weight"), fp.p(pre + "mlp_nums.0.bias"), z1)
+            ops.silu_fwd(z1, a1)
+            ops.linear_fwd(prec, a1, fp.p(pre + "mlp_nums.2.weight"), fp.p(pre + "mlp_nums.2.bias"), ecat[:, nd * E:])
+        a2 = ws.get(f"{tag}.a2", (rows, E))
+        ops.linear_fwd(prec, ecat, fp.p(pre + "mlp_output.0.weight"), fp.p(pre + "mlp_output.0.bias"), a2, act=ACT_RELU)
+        w2 = fp.p(pre + "mlp_output.2.weight")
+        out = ws.get(f"{tag}.out", (rows, w2.shape[0]))
+        ops.linear_fwd(prec, a2, w2, fp.p(pre + "mlp_output.2.bias"), out)
+        return out
+
+    def backward(self, dout, ws: Workspace, tag):
+        fp, pre, E, prec, nd, nn = self.fp, self.prefix, self.E, self.prec, self.nd, self.nn
+        rows = dout.shape[0]
+        x = self._x
+        ecat = ws.get(f"{tag}.ecat", (rows, self.cat_dim))
+        a2 = ws.get(f"{tag}.a2", (rows, E))
+        da2 = ws.get(f"{tag}.da2", (rows, E))
+        ops.linear_bwd_data(prec, dout, fp.p(pre + "mlp_output.2.weight"), da2, relu_of=a2)
+        ops.linear_bwd_weight(prec, dout, a2, fp.g(pre + "mlp_output.2.weight"))
+        ops.colsum(dout, out_sum=fp.g(pre + "mlp_output.2.bias"))
+        decat = ws.get(f"{tag}.decat", (rows, self.cat_dim))
+        ops.linear_bwd_data(prec, da2, fp.p(pre + "mlp_output.0.weight"), decat)
+        ops.linear_bwd_weight(prec, da2, ecat, fp.g(pre + "mlp_output.0.weight"))
+        ops.colsum(da2, out_sum=fp.g(pre + "mlp_output.0.bias"))
+        if nd:
+            gt = fp.ggroup(f"{pre}embeddings_list.0.weight", sum(self.cards), E)
+            ops.embed_bwd(x[:, :nd], decat[:, :nd * E], gt, self.tab_off, self.cards, E)
+        if nn:
+            feats = ws.get(f"{tag}.feats", (rows, 16 * nn))
+            z1 = ws.get(f"{tag}.z1", (rows, 16 * nn))
+            a1 = ws.get(f"{tag}.a1", (rows, 16 * nn))
+            dy1 = decat[:, nd * E:]
+            da1 = ws.get(f"{tag}.da1", (rows, 16 * nn))
+            ops.linear_bwd_data(prec, dy1, fp.p(pre + "mlp_nums.2.weight"), da1)
+            ops.linear_bwd_weight(prec, dy1, a1, fp.g(pre + "mlp_nums.2.weight"))
+            ops.colsum(dy1, out_sum=fp.g(pre + "mlp_nums.2.bias"))
+            dz1 = ws.get(f"{tag}.dz1", (rows, 16 * nn))
+            ops.silu_bwd(z1, da1, dz1)
+            ops.linear_bwd_weight(prec, dz1, feats, fp.g(pre + "mlp_nums.0.weight"))
+            ops.colsum(dz1, out_sum=fp.g(pre + "mlp_nums.0.bias"))
+
+
+def _lin_bwd(prec, dy, x, w, gw, gb, dx=None, relu_of=None, accumulate=False):
+    """Backward of y = x W^T + b: weight/bias grads always, input grad if dx is given."""
+    if dx is not None:
+        ops.linear_bwd_data(prec, dy, w, dx, relu_of=relu_of, accumulate=accumulate)
+    ops.linear_bwd_weight(prec, dy, x, gw)
+    ops.colsum(dy, out_sum=gb)
+
+
+# ---------------------------------------------------------------------------
+class DenoiserEngine:
+    """Launch sequences of BiRNN_score.forward (reference DIFF.py:196-224), its backward,
+    and the fused loss step of get_loss (DIFF.py:252-260)."""
+
+    def __init__(self, module, device, dtype="fp32"):
+        self.prec = prec_of(dtype)
+        self.device = device
+        c = module.cfg
+        self.K, self.H, self.E, self.L, self.steps = c["input_size"], c["hidden_size"], c["emb_dim"], c["num_layers"], c["diffusion_steps"]
+        self.time_dim = c["time_dim"]
+        nb, nc, nn, cards = c["n_bins"], c["n_cats"], c["n_nums"], c["cards"]
+        self.F = nb + nc + nn
+        lstm_dirs = [("lstm.", "_l{l}"), ("lstm.", "_l{l}_reverse")]
+        gru_dirs = [("cond_GRU.", "_l{l}"), ("cond_GRU.", "_l{l}_reverse")]
+        layout = [(n, False) for n in ("input_proj.net.0.weight", "input_proj.net.0.bias", "t_enc.linear_proj.weight",
+                                       "t_enc.linear_proj.bias", "i_enc.linear_proj.weight", "i_enc.linear_proj.bias",
+                                       "proj.net.0.weight", "proj.net.0.bias")]
+        layout += RnnStack.layout(lstm_dirs, self.L)
+        layout += [(n, False) for n in ("layer_norm.weight", "layer_norm.bias", "fc.weight", "fc.bias")]
+        layout += EmbBlock.layout("Emb.", nb + nc, nn)
+        layout += RnnStack.layout(gru_dirs, self.L)
+        layout += [(n, False) for n in ("cond_output.weight", "cond_output.bias", "time_encode.0.weight",
+                                        "time_encode.0.bias", "time_encode.2.weight", "time_encode.2.bias")]
+        inactive = ["Emb_hidden.weight", "Emb_hidden.bias"]
+        self.fp = FlatParams(module, layout, inactive, device)
+        self.lstm = RnnStack(self.fp, CELL_LSTM, self.H, self.H, self.L, lstm_dirs, "bidir", self.prec)
+        self.gru = RnnStack(self.fp, CELL_GRU, self.H, self.E, self.L, gru_dirs, "bidir", self.prec)
+        self.emb = EmbBlock(self.fp, "Emb.", nb, nc, nn, cards, self.E, self.prec)
+        self.ws = Workspace(device)
+        self.scale_t = module.t_enc.scale.to(device=device, dtype=torch.float32).contiguous()
+        self.shift_t = module.t_enc.shift.to(device=device, dtype=torch.float32).contiguous()
+        self.scale_i = module.i_enc.scale.to(device=device, dtype=torch.float32).contiguous()
+        self.shift_i = module.i_enc.shift.to(device=device, dtype=torch.float32).contiguous()
+        self.i_max = float(module.i_enc.max_value)
+
+    # -- forward ------------------------------------------------------------
+    def forward(self, x, t, i_f, time_info, cond, train=False):
+        """x [B,T,K], t [B,T,1], i_f [B,T(,1)] float steps, time_info [B,T,td], cond [B,T,F] ->
+        predicted noise [B,T,K] (a workspace buffer, valid until the next call)."""
+        fp, ws, prec, H, K = self.fp, self.ws, self.prec, self.H, self.K
+        B, T, _ = x.shape
+        BT = B * T
+        if cond.shape[1] != T:
+            raise ValueError("cond must cover the same T steps as x (right-padding a shorter cond is not supported)")
+        if train:
+            self.lstm.pack()
+            self.gru.pack()
+        else:
+            self.lstm.pack_fwd_only()
+            self.gru.pack_fwd_only()
+        x2 = x.reshape(BT, K)
+        t1 = t.reshape(BT)
+        i1 = i_f.reshape(BT)
+        ti2 = time_info.reshape(BT, self.time_dim)
+        c2 = cond.reshape(BT, self.F)
+        self._saved = (x2, t1, i1, ti2, B, T)
+        cat = ws.get("cat", (BT, 4 * H))
+        ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), cat[:, :H])
+        emb = self.emb.forward(c2, ws, "emb")
+        gout = self.gru.forward(emb, B, T, ws, "gru", train)
+        ops.linear_fwd(prec, gout, fp.p("cond_output.weight"), fp.p("cond_output.bias"), cat[:, :H], accumulate=True)
+        ops.posenc_fwd(t1, 1, BT, H, 1.0, fp.p("t_enc.linear_proj.weight"), fp.p("t_enc.linear_proj.bias"), self.scale_t,
+                       self.shift_t, cat[:, H:2 * H])
+        ops.posenc_fwd(i1, 1, BT, H, 1.0 / self.i_max, fp.p("i_enc.linear_proj.weight"), fp.p("i_enc.linear_proj.bias"),
+                       self.scale_i, self.shift_i, cat[:, 2 * H:3 * H])
+        ta = ws.get("ta", (BT, H))
+        ops.linear_fwd(prec, ti2, fp.p("time_encode.0.weight"), fp.p("time_encode.0.bias"), ta, act=ACT_RELU)
+        ops.linear_fwd(prec, ta, fp.p("time_encode.2.weight"), fp.p("time_encode.2.bias"), cat[:, 3 * H:])
+        pa = ws.get("pa", (BT, H))
+        ops.linear_fwd(prec, cat, fp.p("proj.net.0.weight"), fp.p("proj.net.0.bias"), pa, act=ACT_RELU)
+        lout = self.lstm.forward(pa, B, T, ws, "lstm", train)
+        ln = ws.get("ln", (BT, 2 * H))
+        mr = ws.get("mr", (BT, 2))
+        ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, mr)
+        pred = ws.get("pred", (BT, K))
+        ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
+        return pred.view(B, T, K)
+
+    # -- backward -----------------------------------------------------------
+    def backward(self, dpred):
+        """Accumulates d(loss)/d(params) into the flat gradient buffer given d(loss)/d(output)."""
+        fp, ws, prec, H, K = self.fp, self.ws, self.prec, self.H, self.K
+        x2, t1, i1, ti2, B, T = self._saved
+        BT = B * T
+        Lh = H // 2
+        dpred = dpred.reshape(BT, K)
+        cat = ws.get("cat", (BT, 4 * H))
+        ta = ws.get("ta", (BT, H))
+        pa = ws.get("pa", (BT, H))
+        ln = ws.get("ln", (BT, 2 * H))
+        mr = ws.get("mr", (BT, 2))
+        lout = ws.get("lstm.out%d" % (self.L - 1), (BT, 2 * H))
+        gout = ws.get("gru.out%d" % (self.L - 1), (BT, 2 * H))
+        dln = ws.get("dln", (BT, 2 * H))
+        _lin_bwd(prec, dpred, ln, fp.p("fc.weight"), fp.g("fc.weight"), fp.g("fc.bias"), dx=dln)
+        dlout = ws.get("dlout", (BT, 2 * H))
+        ops.layernorm_bwd(dln, lout, fp.p("layer_norm.weight"), mr, dlout, fp.g("layer_norm.weight"), fp.g("layer_norm.bias"))
+        dpz = self.lstm.backward(dlout, ws, "lstm", need_dx=True, relu_of=pa)      # includes the ReLU of proj
+        dcat = ws.get("dcat", (BT, 4 * H))
+        _lin_bwd(prec, dpz, cat, fp.p("proj.net.0.weight"), fp.g("proj.net.0.weight"), fp.g("proj.net.0.bias"), dx=dcat)
+        dxh = dcat[:, :H]
+        _lin_bwd(prec, dxh, x2, None, fp.g("input_proj.net.0.weight"), fp.g("input_proj.net.0.bias"))
+        ops.colsum(dcat[:, H:H + Lh], out_sum=fp.g("t_enc.linear_proj.bias"), row_scale=t1, scale_mul=1.0,
+                   out_wsum=fp.g("t_enc.linear_proj.weight"))
+        ops.colsum(dcat[:, 2 * H:2 * H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
+                   out_wsum=fp.g("i_enc.linear_proj.weight"))
+        dtenc = dcat[:, 3 * H:]
+        dta = ws.get("dta", (BT, H))
+        _lin_bwd(prec, dtenc, ta, fp.p("time_encode.2.weight"), fp.g("time_encode.2.weight"), fp.g("time_encode.2.bias"),
+                 dx=dta, relu_of=ta)
+        _lin_bwd(prec, dta, ti2, None, fp.g("time_encode.0.weight"), fp.g("time_encode.0.bias"))
+        dgout = ws.get("dgout", (BT, 2 * H))
+        _lin_bwd(prec, dxh, gout, fp.p("cond_output.weight"), fp.g("cond_output.weight"), fp.g("cond_output.bias"), dx=dgout)
+        demb = self.gru.backward(dgout, ws, "gru", need_dx=True)
+        self.emb.backward(demb, ws, "emb")
+
+    # -- reverse diffusion --------------------------------------------------
+    def sample_loop(self, x, t, time_info, cond, z_all, betas, alphas, keep=None):
+        """The reverse-diffusion loop of reference DIFF.py:340-351, in place on x [B,T,K].
+        z_all[s] is the noise of step s.  Everything that does not depend on x or on the
+        step (cond path, t_enc, time_encode and their share of `proj`) is evaluated once;
+        i_enc's share of `proj` is a [steps, H] table used as a per-step bias."""
+        fp, ws, prec, H, K = self.fp, self.ws, self.prec, self.H, self.K
+        B, T, _ = x.shape
+        BT = B * T
+        S = z_all.shape[0]
+        self.lstm.pack_fwd_only()
+        self.gru.pack_fwd_only()
+        x2 = x.view(BT, K)
+        cat = ws.get("s.cat", (BT, 4 * H))
+        emb = self.emb.forward(cond.reshape(BT, self.F), ws, "emb")
+        gout = self.gru.forward(emb, B, T, ws, "gru", False)
+        ops.linear_fwd(prec, gout, fp.p("cond_output.weight"), fp.p("cond_output.bias"), cat[:, :H])
+        ops.posenc_fwd(t.reshape(BT), 1, BT, H, 1.0, fp.p("t_enc.linear_proj.weight"), fp.p("t_enc.linear_proj.bias"),
+                       self.scale_t, self.shift_t, cat[:, H:2 * H])
+        cat[:, 2 * H:3 * H].zero_()
+        ta = ws.get("ta", (BT, H))
+        ops.linear_fwd(prec, time_info.reshape(BT, self.time_dim), fp.p("time_encode.0.weight"), fp.p("time_encode.0.bias"),
+                       ta, act=ACT_RELU)
+        ops.linear_fwd(prec, ta, fp.p("time_encode.2.weight"), fp.p("time_encode.2.bias"), cat[:, 3 * H:])
+        pinv = ws.get("s.pinv", (BT, H))
+        wp = fp.p("proj.net.0.weight")
+        ops.linear_fwd(prec, cat, wp, fp.p("proj.net.0.bias"), pinv)
+        steps_f = torch.arange(S, device=self.device, dtype=torch.float32)
+        ie = ws.get("s.ie", (S, H))
+        ops.posenc_fwd(steps_f, 1, S, H, 1.0 / self.i_max, fp.p("i_enc.linear_proj.weight"), fp.p("i_enc.linear_proj.bias"),
+                       self.scale_i, self.shift_i, ie)
+        V = ws.get("s.V", (S, H))
+        ops.linear_fwd(prec, ie, wp[:, 2 * H:3 * H], None, V)
+        xh = ws.get("s.xh", (BT, H))
+        pa = ws.get("pa", (BT, H))
+        ln = ws.get("ln", (BT, 2 * H))
+        pred = ws.get("pred", (BT, K))
+        b32, a32 = betas.float().cpu(), alphas.float().cpu()
+        c1 = (1 / (1 - b32).sqrt()).tolist()
+        c2 = (b32 / (1 - a32).sqrt()).tolist()
+        c3 = b32.sqrt().tolist()
+        for s in range(S - 1, -1, -1):
+            ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
+            ops.linear_fwd(prec, xh, wp[:, :H], V[s], pa, act=ACT_RELU, residual=pinv)
+            lout = self.lstm.forward(pa, B, T, ws, "lstm", False)
+            ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, None)
+            ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
+            ops.sampler_update(x2, pred, z_all[s], c1[s], c2[s], c3[s], s == 0)
+            if keep is not None and s in keep:
+                keep[s] = x.clone()
+        return x
+
+    # -- get_loss + backward ------------------------------------------------
+    def loss_and_grads(self, x0, t, i_idx, noise, time_info, cond, alphas, loss_sum, global_numel=None):
+        """add_noise -> forward -> MSE -> backward.  loss_sum[0] += sum of squared errors of
+        this rank's slice; gradients are scaled by 2/global_numel so that a sum over ranks
+        equals the gradient of the global mean loss."""
+        B, T, K = x0.shape
+        xn = self.ws.get("x_noisy", (B, T, K))
+        i_f = self.ws.get("i_f", (B, T))
+        ops.add_noise(x0, noise, i_idx, alphas, xn, i_f)
+        pred = self.forward(xn, t, i_f, time_info, cond, train=True)
+        dpred = self.ws.get("dpred", (B, T, K))
+        n = global_numel if global_numel is not None else pred.numel()
+        ops.mse_loss(pred, noise, 2.0 / n, dpred, loss_sum)
+        self.backward(dpred)
+        return pred
+
+
+# ---------------------------------------------------------------------------
+class VAEEngine:
+    """Launch sequences of DeapStack.encoder/decoder/forward (reference VAE.py:152-220), the
+    mixed masked loss (VAE.py:222-253, 350-352) and their backward."""
+
+    def __init__(self, module, device, dtype="fp32"):
+        self.prec = prec_of(dtype)
+        self.device = device
+        c = module.cfg
+        self.F, self.H, self.E, self.L, self.lat = c["input_size"], c["hidden_size"], c["emb_dim"], c["num_layers"], c["lat_dim"]
+        self.nb, self.nc, self.nn, self.cards = c["n_bins"], c["n_cats"], c["n_nums"], list(c["cards"])[:c["n_cats"]]
+        nb, nc, nn = self.nb, self.nc, self.nn
+        enc_dirs = [("encoder_mu.", "_l{l}"), ("encoder_logvar.", "_l{l}")]
+        layout = EmbBlock.layout("Emb.", nb + nc, nn)
+        layout += RnnStack.layout(enc_dirs, self.L)
+        layout += [(n, False) for n in ("fc_mu.weight", "fc_mu.bias", "fc_logvar.weight", "fc_logvar.bias",
+                                        "decoder_mlp.0.weight", "decoder_mlp.0.bias", "decoder_mlp.2.weight",
+                                        "decoder_mlp.2.bias")]
+        layout += EmbBlock.layout("Emb_decoder.", nb + nc, nn)
+        layout += [("Emb_hidden_decoder.weight", False), ("Emb_hidden_decoder.bias", False)]
+        head_w, head_b = [], []
+        if nb:
+            head_w.append("bins_linear.weight"); head_b.append("bins_linear.bias")
+        for j in range(nc):
+            head_w.append(f"cats_linears.{j}.weight"); head_b.append(f"cats_linears.{j}.bias")
+        if nn:
+            head_w.append("nums_linear.weight"); head_b.append("nums_linear.bias")
+        layout += [(n, k > 0) for k, n in enumerate(head_w)] + [(n, k > 0) for k, n in enumerate(head_b)]
+        self.head_w0, self.head_b0 = head_w[0], head_b[0]
+        self.NH = nb + sum(self.cards) + nn
+        inactive = ["time_encode.0.weight", "time_encode.0.bias", "time_encode.2.weight", "time_encode.2.bias"]
+        self.fp = FlatParams(module, layout, inactive, device)
+        self.enc = RnnStack(self.fp, CELL_GRU, self.H, self.F, self.L, enc_dirs, "heads", self.prec)
+        self.emb = EmbBlock(self.fp, "Emb.", nb, nc, nn, self.cards, self.E, self.prec)
+        self.emb_dec = EmbBlock(self.fp, "Emb_decoder.", nb, nc, nn, self.cards, self.E, self.prec)
+        self.ws = Workspace(device)
+
+    def encoder(self, inp, eps, train=False, tag="enc", kld_sum=None):
+        fp, ws, prec, H, Lt = self.fp, self.ws, self.prec, self.H, self.lat
+        B, T, _ = inp.shape
+        BT = B * T
+        if train:
+            self.enc.pack()
+        else:
+            self.enc.pack_fwd_only()
+        x2 = inp.reshape(BT, self.F)
+        e = self.emb.forward(x2, ws, "emb")
+        hh = self.enc.forward(e, B, T, ws, tag, train)
+        mu = ws.get("mu", (BT, Lt))
+        lv = ws.get("lv", (BT, Lt))
+        ops.linear_fwd(prec, hh[:, :H], fp.p("fc_mu.weight"), fp.p("fc_mu.bias"), mu)
+        ops.linear_fwd(prec, hh[:, H:], fp.p("fc_logvar.weight"), fp.p("fc_logvar.bias"), lv)
+        z = ws.get("z", (BT, Lt))
+        eps2 = eps.reshape(BT, Lt)
+        ops.vae_reparam_fwd(mu, lv, eps2, z, kld_sum)
+        self._enc_saved = (hh, eps2, B, T)
+        return z.view(B, T, Lt), mu.view(B, T, Lt), lv.view(B, T, Lt)
+
+    def decoder(self, z, mask, cond, target=None, scales=None, loss_parts=None, train=False):
+        """z [B,T,L], mask [B,T,F] float, cond [B,T,F] or None -> fused head outputs [B*T, NH]
+        (bins | cats | nums, reference-visible values).  With ``target``/``scales``/``loss_parts``
+        the loss partial sums are accumulated and, if train, d(loss)/d(head pre-activations)
+        is left in the 'dheads' workspace buffer."""
+        fp, ws, prec, H = self.fp, self.ws, self.prec, self.H
+        B, T, Lt = z.shape
+        BT = B * T
+        z2 = z.reshape(BT, Lt)
+        m2 = mask.reshape(BT, self.F)
+        d1 = ws.get("d1", (BT, H))
+        ops.linear_fwd(prec, z2, fp.p("decoder_mlp.0.weight"), fp.p("decoder_mlp.0.bias"), d1, act=ACT_RELU)
+        lat = ws.get("lat", (BT, H))
+        ops.linear_fwd(prec, d1, fp.p("decoder_mlp.2.weight"), fp.p("decoder_mlp.2.bias"), lat)
+        ce = None
+        if cond is not None:
+            ce = self.emb_dec.forward(cond.reshape(BT, self.F), ws, "embdec")
+            ops.linear_fwd(prec, ce, fp.p("Emb_hidden_decoder.weight"), fp.p("Emb_hidden_decoder.bias"), lat, accumulate=True)
+        heads = ws.get("heads", (BT, self.NH))
+        ops.linear_fwd(prec, lat, fp.pgroup(self.head_w0, self.NH, H), fp.pgroup(self.head_b0, 1, self.NH), heads)
+        dheads = ws.get("dheads", (BT, self.NH)) if train else None
+        t2 = target.reshape(BT, self.F) if target is not None else m2
+        s = scales if scales is not None else (0.0, 0.0, 0.0)
+        ops.vae_heads_loss(heads, m2, t2, self.nb, self.nc, self.nn, self.cards, s[0], s[1], s[2], dheads, loss_parts)
+        self._dec_saved = (z2, ce, B, T)
+        return heads
+
+    def split_heads(self, heads, B, T):
+        """Fused [B*T, NH] head buffer -> the reference's dict {'bins','cats','nums'} (copies)."""
+        out = {}
+        o = 0
+        if self.nb:
+            out["bins"] = heads[:, o:o + self.nb].reshape(B, T, self.nb).clone()
+            o += self.nb
+        if self.nc:
+            out["cats"] = []
+            for c in self.cards:
+                out["cats"].append(heads[:, o:o + c].reshape(B, T, c).clone())
+                o += c
+        if self.nn:
+            out["nums"] = heads[:, o:o + self.nn].reshape(B, T, self.nn).clone()
+        return out
+
+    def loss_scales(self, global_rows):
+        """(scale_bce, scale_ce, scale_mse): d(mean-reduced loss terms)/d(sum terms) for a global
+        batch of ``global_rows`` = B*T rows (VAE.py:241-251)."""
+        s_bce = 1.0 / (global_rows * self.nb) if self.nb else 0.0
+        s_ce = 1.0 / (global_rows * self.nc) if self.nc else 0.0
+        s_mse = 2.0 / (global_rows * self.nn) if self.nn else 0.0
+        return s_bce, s_ce, s_mse
+
+    def total_loss(self, parts, kld_sum, beta, rows):
+        """Host-side combination of the partial sums (parts: [2+nc] list, kld_sum float)."""
+        bce = parts[0] / (rows * self.nb) if self.nb else 0.0
+        mse = parts[1] / (rows * self.nn) if self.nn else 0.0
+        ce = sum(parts[2:2 + self.nc]) / (rows * self.nc) if self.nc else 0.0
+        kld = -0.5 * kld_sum / (rows * self.lat)
+        return mse + bce + ce + beta * kld, dict(bce=bce, ce=ce, mse=mse, kld=kld)
+
+    def backward(self, beta, global_rows):
+        """Backward of loss = mse + bce + ce + beta*kld through decoder and encoder (after
+        encoder(train=True) and decoder(train=True))."""
+        fp, ws, prec, H, Lt = self.fp, self.ws, self.prec, self.H, self.lat
+        z2, ce, B, T = self._dec_saved
+        hh, eps2, _, _ = self._enc_saved
+        BT = B * T
+        dheads = ws.get("dheads", (BT, self.NH))
+        lat = ws.get("lat", (BT, H))
+        d1 = ws.get("d1", (BT, H))
+        mu = ws.get("mu", (BT, Lt))
+        lv = ws.get("lv", (BT, Lt))
+        dlat = ws.get("dlat", (BT, H))
+        _lin_bwd(prec, dheads, lat, fp.pgroup(self.head_w0, self.NH, H), fp.ggroup(self.head_w0, self.NH, H),
+                 fp.ggroup(self.head_b0, 1, self.NH), dx=dlat)
+        if ce is not None:
+            dce = ws.get("dce", (BT, self.F))
+            _lin_bwd(prec, dlat, ce, fp.p("Emb_hidden_decoder.weight"), fp.g("Emb_hidden_decoder.weight"),
+                     fp.g("Emb_hidden_decoder.bias"), dx=dce)
+            self.emb_dec.backward(dce, ws, "embdec")
+        dd1 = ws.get("dd1", (BT, H))
+        _lin_bwd(prec, dlat, d1, fp.p("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.bias"),
+                 dx=dd1, relu_of=d1)
+        dz = ws.get("dz", (BT, Lt))
+        _lin_bwd(prec, dd1, z2, fp.p("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.bias"), dx=dz)
+        dmu = ws.get("dmu", (BT, Lt))
+        dlv = ws.get("dlv", (BT, Lt))
+        ops.vae_reparam_bwd(dz, mu, lv, eps2, beta / (global_rows * Lt), dmu, dlv)
+        dhh = ws.get("dhh", (BT, 2 * H))
+        _lin_bwd(prec, dmu, hh[:, :H], fp.p("fc_mu.weight"), fp.g("fc_mu.weight"), fp.g("fc_mu.bias"), dx=dhh[:, :H])
+        _lin_bwd(prec, dlv, hh[:, H:], fp.p("fc_logvar.weight"), fp.g("fc_logvar.weight"), fp.g("fc_logvar.bias"), dx=dhh[:, H:])
+        de = self.enc.backward(dhh, ws, "enc", need_dx=True)
+        self.emb.backward(de, ws, "emb")
