@@ -144,7 +144,7 @@ def backward(sd, cache, dout, schema: Schema):
 # ----------------------------------------------------------------------------
 # get_loss -- DIFF.py:252-260 with the random draws (i, noise) passed in
 def loss_and_grads(sd, x0, t, i_idx, noise, time_info, cond, schema, alphas, want_grads=True,
-                   diffusion_steps=100, num_layers=2):
+                   diffusion_steps=100, num_layers=2, global_numel=None):
     dt = x0.dtype
     B, T, K = x0.shape
     x_noisy = ops.add_noise(x0, i_idx, noise, alphas)
@@ -154,6 +154,7 @@ def loss_and_grads(sd, x0, t, i_idx, noise, time_info, cond, schema, alphas, wan
     loss = float(np.mean(diff.astype(np.float64) ** 2))
     if not want_grads:
         return loss, pred, None
-    dout = (2.0 / diff.size) * diff
+    # under data parallelism each rank scales by the GLOBAL batch's element count
+    dout = (2.0 / (global_numel if global_numel is not None else diff.size)) * diff
     grads = backward(sd, cache, dout.astype(dt), schema)
     return loss, pred, grads

@@ -25,9 +25,44 @@ def silu_grad(x):
 
 
 # ----------------------------------------------------------------------------
+# Matrix products.  With operand rounding switched on (``with bf16_operands():``) every
+# product that the HIP path evaluates on bf16 matrix cores rounds BOTH operands to bf16
+# (round-to-nearest-even) and accumulates in the working dtype -- the documented
+# semantics of the bf16 compute mode.  Off by default (plain float products).
+_ROUND_OPERANDS = False
+
+
+def bf16_round(a):
+    """Round float32 values to the nearest bfloat16 (ties to even), returned as float32."""
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32).reshape(a32.shape)
+
+
+class bf16_operands:
+    def __enter__(self):
+        global _ROUND_OPERANDS
+        self.prev = _ROUND_OPERANDS
+        _ROUND_OPERANDS = True
+
+    def __exit__(self, *exc):
+        global _ROUND_OPERANDS
+        _ROUND_OPERANDS = self.prev
+
+
+def mm(a, b):
+    """a @ b on the (emulated) matrix cores."""
+    if _ROUND_OPERANDS:
+        dt = np.result_type(a, b)
+        return (bf16_round(a).astype(np.float64) @ bf16_round(b).astype(np.float64)).astype(dt)
+    return a @ b
+
+
+# ----------------------------------------------------------------------------
 # nn.Linear: y = x W^T + b   (weights are [out, in] as in torch)
 def linear_fwd(x, W, b=None):
-    y = x @ W.T
+    y = mm(x, W.T)
     if b is not None:
         y = y + b
     return y
@@ -39,9 +74,9 @@ def linear_bwd(x, W, dy, need_dx=True):
     N = W.shape[0]
     x2 = x.reshape(-1, K)
     dy2 = dy.reshape(-1, N)
-    dW = dy2.T @ x2
+    dW = mm(dy2.T, x2)
     db = dy2.sum(0)
-    dx = (dy2 @ W).reshape(x.shape) if need_dx else None
+    dx = mm(dy2, W).reshape(x.shape) if need_dx else None
     return dx, dW, db
 
 

@@ -7,7 +7,7 @@ GRU), which is what the reference's ``nn.LSTM`` (DIFF.py:182) and ``nn.GRU``
 """
 import numpy as np
 
-from .ops import sigmoid
+from .ops import mm, sigmoid
 
 
 def _sfx(layer, reverse):
@@ -19,7 +19,7 @@ def lstm_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
     B, T, _ = x.shape
     H = Whh.shape[1]
     dt = x.dtype
-    xp = x @ Wih.T + bih + bhh
+    xp = mm(x, Wih.T) + bih + bhh
     h = np.zeros((B, H), dt)
     c = np.zeros((B, H), dt)
     hs = np.zeros((B, T, H), dt)
@@ -27,7 +27,7 @@ def lstm_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
     cs = np.zeros((B, T, H), dt)
     order = range(T - 1, -1, -1) if reverse else range(T)
     for t in order:
-        a = xp[:, t] + h @ Whh.T
+        a = xp[:, t] + mm(h, Whh.T)
         i = sigmoid(a[:, :H])
         f = sigmoid(a[:, H:2 * H])
         g = np.tanh(a[:, 2 * H:3 * H])
@@ -69,12 +69,12 @@ def lstm_dir_bwd(Wih, Whh, cache, dhs, need_dx=True):
         dc_next = dc * f
         da_t = np.concatenate([di * i * (1 - i), df * f * (1 - f), dg * (1 - g * g), do * o * (1 - o)], -1)
         da[:, t] = da_t
-        dh_next = da_t @ Whh
+        dh_next = mm(da_t, Whh)
     da2 = da.reshape(B * T, 4 * H)
-    dWih = da2.T @ x.reshape(B * T, -1)
-    dWhh = da2.T @ hprev_all.reshape(B * T, H)
+    dWih = mm(da2.T, x.reshape(B * T, -1))
+    dWhh = mm(da2.T, hprev_all.reshape(B * T, H))
     db = da2.sum(0)
-    dx = (da2 @ Wih).reshape(x.shape) if need_dx else None
+    dx = mm(da2, Wih).reshape(x.shape) if need_dx else None
     return dx, dWih, dWhh, db, db.copy()
 
 
@@ -83,13 +83,13 @@ def gru_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
     B, T, _ = x.shape
     H = Whh.shape[1]
     dt = x.dtype
-    xp = x @ Wih.T + bih
+    xp = mm(x, Wih.T) + bih
     h = np.zeros((B, H), dt)
     hs = np.zeros((B, T, H), dt)
     stash = np.zeros((B, T, 4 * H), dt)       # r, z, n, hp_n
     order = range(T - 1, -1, -1) if reverse else range(T)
     for t in order:
-        hp = h @ Whh.T + bhh
+        hp = mm(h, Whh.T) + bhh
         r = sigmoid(xp[:, t, :H] + hp[:, :H])
         z = sigmoid(xp[:, t, H:2 * H] + hp[:, H:2 * H])
         n = np.tanh(xp[:, t, 2 * H:] + r * hp[:, 2 * H:])
@@ -126,14 +126,14 @@ def gru_dir_bwd(Wih, Whh, cache, dhs, need_dx=True):
         dxp[:, t] = np.concatenate([dar, daz, dan], -1)
         dhp_t = np.concatenate([dar, daz, dan * r], -1)
         dhp[:, t] = dhp_t
-        dh_next = dh * z + dhp_t @ Whh
+        dh_next = dh * z + mm(dhp_t, Whh)
     dxp2 = dxp.reshape(B * T, 3 * H)
     dhp2 = dhp.reshape(B * T, 3 * H)
-    dWih = dxp2.T @ x.reshape(B * T, -1)
-    dWhh = dhp2.T @ hprev_all.reshape(B * T, H)
+    dWih = mm(dxp2.T, x.reshape(B * T, -1))
+    dWhh = mm(dhp2.T, hprev_all.reshape(B * T, H))
     dbih = dxp2.sum(0)
     dbhh = dhp2.sum(0)
-    dx = (dxp2 @ Wih).reshape(x.shape) if need_dx else None
+    dx = mm(dxp2, Wih).reshape(x.shape) if need_dx else None
     return dx, dWih, dWhh, dbih, dbhh
 
 

@@ -1,0 +1,387 @@
+"""Model-level parity on the GPU: the HIP path (through the drop-in Python interface and
+the C ABI) against golden vectors produced by the reference, against the numpy oracle on
+fresh seeded inputs, and through size-independent properties at full benchmark sizes.
+
+Tolerances: fp32 path 1e-4 relative (north star); bf16 path stated per test."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_util as fu
+from oracle import denoiser as oden
+from oracle import ops as oops
+from oracle import vae as ovae
+from oracle.denoiser import Schema
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+BF16_OUT_TOL = 3e-2      # bf16 path vs the fp32 reference: outputs / loss, max-norm relative
+BF16_GRAD_TOL = 1e-1     # bf16 path vs the fp32 reference: gradients, relative L2 per tensor (H >= 200 shapes)
+BF16_EMU_TOL = 5e-3      # bf16 path vs the oracle with operands rounded to bf16 at the same points: outputs
+BF16_EMU_GRAD_TOL = 2e-2  # ... gradients, relative L2 per tensor
+
+
+def grad_err(a, b, dtype):
+    """fp32: max-norm relative error; bf16: relative L2 error of the tensor."""
+    if dtype == "fp32":
+        return fu.rel_err(a, b)
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev(lib):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _schema(meta):
+    s = meta["schema"]
+    return Schema(s["n_bins"], s["n_cats"], s["n_nums"], list(s["cards"]))
+
+
+def T_(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _make_denoiser(meta, sch, dev, dtype, sd=None):
+    from timeautodiff_amd import DIFF
+    F = sch.n_bins + sch.n_cats + sch.n_nums
+    torch.manual_seed(meta["seed"])
+    m = DIFF.BiRNN_score(meta["K"], F, meta["H"], 2, 100, 8, meta["E"], sch.n_bins, sch.n_cats, sch.n_nums, sch.cards)
+    if sd is not None:
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.set_compute_dtype(dtype)
+    return m
+
+
+def _denoiser_step(m, dev, data, t, i_idx, noise):
+    from timeautodiff_amd import DIFF
+    eng = m.engine(dev)
+    eng.fp.zero_grad()
+    ls = torch.zeros(1, device=dev)
+    pred = eng.loss_and_grads(T_(data["latent"], dev), T_(t, dev), T_(i_idx.astype(np.int32), dev), T_(noise, dev),
+                              T_(data["time_info"], dev), T_(data["cond"], dev), DIFF.alphas.to(dev), ls)
+    torch.cuda.synchronize()
+    grads = {k: eng.fp.g(k).cpu().numpy() for k in eng.fp.offsets if eng.fp.offsets[k] < eng.fp.n_active}
+    return pred.cpu().numpy(), ls.item() / pred.numel(), grads
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["den_numeric_small", "den_mixed_small", "den_metro_small"])
+def test_denoiser_vs_reference_golden(dev, name, dtype):
+    z, meta = fu.load(name)
+    sch = _schema(meta)
+    sd = fu.sub(z, "w")
+    m = _make_denoiser(meta, sch, dev, dtype, sd)
+    assert list(m.state_dict().keys()) == list(sd.keys())           # same keys, same order as the reference
+    data = fu.make_data(meta["schema"], N=meta["B"], T=meta["T"], K=meta["K"], seed=meta["seed"], mask_kind="bern")
+    pred, loss, grads = _denoiser_step(m, dev, data, z["t"], z["i_idx"], z["noise"])
+    gref = fu.sub(z, "g")
+    assert set(gref) == set(grads)
+    if dtype == "fp32":
+        assert fu.rel_err(pred, z["pred"]) < TOL
+        assert abs(loss - float(z["loss"])) < TOL * float(z["loss"])
+        errs = {k: grad_err(grads[k], gref[k], dtype) for k in gref}
+        print("worst grad errors:", sorted(errs.items(), key=lambda kv: -kv[1])[:4])
+        assert max(errs.values()) < TOL, errs
+    else:
+        # (a) against the oracle with the SAME rounding points (operands of every matrix product
+        # rounded to bf16, fp32 accumulation): only accumulation order and rare rounding flips differ
+        _, alphas = oops.schedule(100)
+        with oops.bf16_operands():
+            oloss, opred, ograds = oden.loss_and_grads(sd, data["latent"], z["t"], z["i_idx"], z["noise"], data["time_info"],
+                                                       data["cond"], sch, alphas)
+        assert fu.rel_err(pred, opred) < BF16_EMU_TOL
+        assert abs(loss - oloss) < BF16_EMU_TOL * oloss
+        errs = {k: grad_err(grads[k], ograds[k].reshape(grads[k].shape), dtype) for k in gref}
+        print("worst grad errors vs bf16-emulating oracle:", sorted(errs.items(), key=lambda kv: -kv[1])[:4])
+        assert max(errs.values()) < BF16_EMU_GRAD_TOL, errs
+        # (b) against the fp32 reference: the stated looser bf16 tolerance on outputs and loss
+        assert fu.rel_err(pred, z["pred"]) < BF16_OUT_TOL
+        assert abs(loss - float(z["loss"])) < BF16_OUT_TOL * float(z["loss"])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_denoiser_h200_vs_reference_golden(dev, dtype):
+    """The stock_data shape (H=200, T=24, emb 128): weights re-created from the seed."""
+    z, meta = fu.load("den_numeric_h200")
+    sch = _schema(meta)
+    m = _make_denoiser(meta, sch, dev, dtype)
+    ws = fu.sub(z, "ws")
+    for k, v in m.state_dict().items():
+        assert np.allclose(fu.stats(v.cpu().numpy()), ws[k], rtol=1e-12, atol=1e-12), k
+    data = fu.make_data(meta["schema"], N=meta["B"], T=meta["T"], K=meta["K"], seed=meta["seed"], mask_kind="bern")
+    pred, loss, grads = _denoiser_step(m, dev, data, z["t"], z["i_idx"], z["noise"])
+    ot, gt = (TOL, TOL) if dtype == "fp32" else (BF16_OUT_TOL, BF16_GRAD_TOL)
+    assert fu.rel_err(pred, z["pred"]) < ot
+    gs, gh = fu.sub(z, "gs"), fu.sub(z, "gh")
+    assert set(gs) == set(grads)
+    for k in gs:
+        n = gs[k][1]
+        assert abs(np.linalg.norm(grads[k].astype(np.float64)) - n) < gt * max(n, 1e-12), k
+        assert np.max(np.abs(grads[k].ravel()[:64] - gh[k])) < gt * max(np.max(np.abs(grads[k])), 1e-12), k
+
+
+def test_denoiser_module_call_and_state_dict(dev):
+    """Drop-in surface: model(x, t, i, time_info, cond, mask), state_dict round trip, in-place edits."""
+    z, meta = fu.load("den_mixed_small")
+    sch = _schema(meta)
+    sd = fu.sub(z, "w")
+    m = _make_denoiser(meta, sch, dev, "fp32", sd)
+    data = fu.make_data(meta["schema"], N=meta["B"], T=meta["T"], K=meta["K"], seed=meta["seed"], mask_kind="bern")
+    B, T = meta["B"], meta["T"]
+    i = torch.from_numpy(z["i_idx"]).view(-1, 1, 1).expand(B, T, 1).float()
+    out = m(torch.from_numpy(z["x_noisy"]), torch.from_numpy(z["t"]), i, torch.from_numpy(data["time_info"]),
+            torch.from_numpy(data["cond"]), None)
+    assert out.is_cuda and fu.rel_err(out.cpu().numpy(), z["pred"]) < TOL
+    sd2 = m.state_dict()
+    for k in sd:
+        assert np.array_equal(sd2[k].cpu().numpy(), sd[k]), k
+    # a second model loaded from the first gives the same output; zeroed fc gives the bias
+    m2 = _make_denoiser(dict(meta, seed=999), sch, dev, "fp32")
+    m2.load_state_dict(sd2)
+    out2 = m2(torch.from_numpy(z["x_noisy"]), torch.from_numpy(z["t"]), i, torch.from_numpy(data["time_info"]),
+              torch.from_numpy(data["cond"]), None)
+    assert torch.equal(out, out2)
+    with torch.no_grad():
+        m2.fc.weight.zero_()
+    out3 = m2(torch.from_numpy(z["x_noisy"]), torch.from_numpy(z["t"]), i, torch.from_numpy(data["time_info"]),
+              torch.from_numpy(data["cond"]), None)
+    assert fu.rel_err(out3.cpu().numpy(), np.broadcast_to(sd["fc.bias"], out3.shape)) < 1e-6
+
+
+# ------------------------------------------------------------------ VAE
+def _make_vae(meta, sch, dev, dtype, sd=None):
+    from timeautodiff_amd import VAE
+    F = sch.n_bins + sch.n_cats + sch.n_nums
+    torch.manual_seed(meta["seed"])
+    ae = VAE.DeapStack(1, sch.n_bins, sch.n_cats, sch.n_nums, sch.cards, F, meta["H"], 2, meta["E"], 8, meta["L"])
+    if sd is not None:
+        ae.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ae.set_compute_dtype(dtype)
+    return ae
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["vae_numeric_small", "vae_mixed_small", "vae_metro_small"])
+def test_vae_vs_reference_golden(dev, name, dtype):
+    z, meta = fu.load(name)
+    sch = _schema(meta)
+    sd = fu.sub(z, "w")
+    ae = _make_vae(meta, sch, dev, dtype, sd)
+    assert list(ae.state_dict().keys()) == list(sd.keys())
+    data = fu.make_data(meta["schema"], N=meta["B"], T=meta["T"], K=meta["L"], seed=meta["seed"], mask_kind=meta["mask_kind"])
+    B, T = meta["B"], meta["T"]
+    rows = B * T
+    eng = ae.engine(dev)
+    inp = T_(data["response"] + data["cond"], dev)
+    mask = T_(data["mask"], dev)
+    cond = T_(data["cond"], dev)
+    target = inp * mask
+    beta = meta["beta"]
+    parts = torch.zeros(3 + max(sch.n_cats, 1), device=dev)
+    eng.fp.zero_grad()
+    zz, mu, lv = eng.encoder(inp, T_(z["eps"], dev), train=True, kld_sum=parts[2 + max(sch.n_cats, 1):])
+    heads = eng.decoder(zz, mask, cond, target=target, scales=eng.loss_scales(rows), loss_parts=parts, train=True)
+    eng.backward(beta, rows)
+    torch.cuda.synchronize()
+    gref = fu.sub(z, "g")
+    grads = {k: eng.fp.g(k).cpu().numpy() for k in eng.fp.offsets if eng.fp.offsets[k] < eng.fp.n_active}
+    assert set(gref) == set(grads)
+    out = eng.split_heads(heads, B, T)
+    p = parts.tolist()
+    total, pr = eng.total_loss(p[:2 + sch.n_cats], p[2 + max(sch.n_cats, 1)], beta, rows)
+    if dtype == "fp32":
+        ref = dict(mu=z["mu"], lv=z["lv"], z=z["z"], loss=float(z["loss"]), kld=float(z["kld"]))
+        if sch.n_bins:
+            ref["bins"] = z["out/bins"]
+        ref["cats"] = [z[f"out/cats{j}"] for j in range(sch.n_cats)]
+        if sch.n_nums:
+            ref["nums"] = z["out/nums"]
+        ot, gt, gr = TOL, TOL, gref
+    else:
+        # the oracle with operands rounded to bf16 at the same points as the kernels
+        with oops.bf16_operands():
+            ototal, ores, ograds = ovae.loss_and_grads(sd, data["response"] + data["cond"], data["mask"], data["cond"], z["eps"],
+                                                       np.float32(beta), sch)
+        ref = dict(mu=ores["mu"], lv=ores["lv"], z=ores["z"], loss=ototal, kld=ores["parts"]["kld"],
+                   cats=ores["out"].get("cats", []))
+        for k in ("bins", "nums"):
+            if k in ores["out"]:
+                ref[k] = ores["out"][k]
+        ot, gt, gr = BF16_EMU_TOL, BF16_EMU_GRAD_TOL, {k: v.reshape(grads[k].shape) for k, v in ograds.items()}
+        # and the stated looser tolerance against the fp32 reference
+        assert fu.rel_err(zz.cpu().numpy(), z["z"]) < BF16_OUT_TOL
+        assert abs(total - float(z["loss"])) < BF16_OUT_TOL * abs(float(z["loss"]))
+    assert fu.rel_err(mu.cpu().numpy(), ref["mu"]) < ot
+    assert fu.rel_err(lv.cpu().numpy(), ref["lv"]) < ot
+    assert fu.rel_err(zz.cpu().numpy(), ref["z"]) < ot
+    if sch.n_bins:
+        assert fu.rel_err(out["bins"].cpu().numpy(), ref["bins"]) < ot
+    for j in range(sch.n_cats):
+        assert fu.rel_err(out["cats"][j].cpu().numpy(), ref["cats"][j]) < ot
+    if sch.n_nums:
+        assert fu.rel_err(out["nums"].cpu().numpy(), ref["nums"]) < ot
+    assert abs(total - ref["loss"]) < ot * abs(ref["loss"])
+    assert abs(pr["kld"] - ref["kld"]) < ot * abs(ref["kld"])
+    errs = {k: grad_err(grads[k], gr[k], dtype) for k in gref}
+    print("worst grad errors:", sorted(errs.items(), key=lambda kv: -kv[1])[:4])
+    assert max(errs.values()) < gt, errs
+
+
+def test_vae_module_surface(dev):
+    """ae.encoder / ae.decoder / ae(x, mask, cond) as the reference's drivers call them."""
+    z, meta = fu.load("vae_mixed_small")
+    sch = _schema(meta)
+    ae = _make_vae(meta, sch, dev, "fp32", fu.sub(z, "w"))
+    data = fu.make_data(meta["schema"], N=meta["B"], T=meta["T"], K=meta["L"], seed=meta["seed"], mask_kind=meta["mask_kind"])
+    inp = torch.from_numpy(data["response"] + data["cond"])
+    out, emb, mu, lv = ae(inp, torch.from_numpy(data["mask"]), torch.from_numpy(data["cond"]), eps=torch.from_numpy(z["eps"]))
+    assert set(out.keys()) == {"bins", "cats", "nums"} and len(out["cats"]) == 2
+    assert fu.rel_err(emb.cpu().numpy(), z["z"]) < TOL and fu.rel_err(out["nums"].cpu().numpy(), z["out/nums"]) < TOL
+    dec = ae.decoder(torch.from_numpy(z["z"]), torch.from_numpy(data["mask"]), torch.from_numpy(data["cond"]))
+    assert fu.rel_err(dec["bins"].cpu().numpy(), z["out/bins"]) < TOL
+    # auto_loss on decoded outputs reproduces the reference's (disc, num)
+    from timeautodiff_amd import VAE
+    target = (inp * torch.from_numpy(data["mask"])).to(dev)
+    disc, num = VAE.auto_loss(target, out, sch.n_bins, sch.n_nums, sch.n_cats, sch.cards)
+    assert abs(float(disc) - float(z["disc"])) < TOL * float(z["disc"])
+    assert abs(float(num) - float(z["num"])) < TOL * max(float(z["num"]), 1e-9)
+
+
+# ------------------------------------------------------------------ loops
+def test_sampler_trajectory_vs_reference_golden(dev):
+    from timeautodiff_amd import DIFF
+    z, meta = fu.load("sampler_mixed_small")
+    sch = _schema(meta)
+    m = _make_denoiser(meta, sch, dev, "fp32", fu.sub(z, "w"))
+    B, T, K = meta["B"], meta["T"], meta["K"]
+    data = fu.make_data(meta["schema"], N=B, T=T, K=K, seed=meta["seed"], mask_kind="ones")
+    torch.manual_seed(meta["seed"] + 7)
+    tgrid = torch.linspace(0, 1, T).view(1, -1, 1).repeat(B, 1, 1)
+    keep = {99: None, 50: None, 1: None}
+    x = DIFF.sample(tgrid, B, T, K, 100, m, torch.from_numpy(data["time_info"]), torch.from_numpy(data["cond"]), None, keep=keep)
+    assert fu.rel_err(keep[99].cpu().numpy(), z["x_after_99"]) < TOL
+    assert fu.rel_err(keep[50].cpu().numpy(), z["x_after_50"]) < TOL
+    assert fu.rel_err(keep[1].cpu().numpy(), z["x_after_1"]) < TOL
+    assert fu.rel_err(x.cpu().numpy(), z["x_final"]) < TOL
+
+
+def test_train_diffusion_loss_curve_vs_reference_golden(dev):
+    from timeautodiff_amd import DIFF
+    from test_host_logic import StubParser
+    z, meta = fu.load("diffloop_numeric")
+    N, T, K, H, steps = meta["N"], meta["T"], meta["K"], meta["H"], meta["steps"]
+    data = fu.make_data(meta["schema"], N=N, T=T, K=K, seed=meta["seed"], mask_kind="ones")
+    dd = dict(parser=StubParser(meta["schema"]), cond_train=torch.from_numpy(data["cond"]),
+              time_info_train=torch.from_numpy(data["time_info"]), target_mask_train=torch.from_numpy(data["mask"]))
+    random.seed(meta["seed"])
+    torch.manual_seed(meta["seed"])
+    losses = []
+    model = DIFF.train_diffusion(torch.from_numpy(data["latent"]), None, dd, H, 2, 100, steps, losses=losses)
+    ref = z["losses"]
+    assert len(losses) == steps
+    assert np.max(np.abs(np.array(losses) - ref) / np.abs(ref)) < 1e-3          # fixed-seed loss-curve window
+    ws = fu.sub(z, "ws")
+    sd = model.state_dict()
+    for k in ws:
+        if not k.startswith("Emb_hidden"):
+            assert abs(fu.stats(sd[k].cpu().numpy())[1] - ws[k][1]) < 1e-3 * max(ws[k][1], 1e-6), k
+    # and the sampler on the trained model reproduces the reference's sample
+    Bs = meta["Bs"]
+    torch.manual_seed(meta["seed"] + 7)
+    tgrid = torch.linspace(0, 1, T).view(1, -1, 1).repeat(Bs, 1, 1)
+    x = DIFF.sample(tgrid, Bs, T, K, 100, model, torch.from_numpy(data["time_info"][:Bs]), torch.from_numpy(data["cond"][:Bs]), None)
+    assert fu.rel_err(x.cpu().numpy(), z["sample"]) < 5e-3
+
+
+@pytest.mark.parametrize("name,fn", [("vaeloop_mixed_val", "train_autoencoder"), ("vaeloop_mixed_train", "train_autoencoder_best_train")])
+def test_train_autoencoder_loss_curve_vs_reference_golden(dev, name, fn):
+    from timeautodiff_amd import VAE
+    from test_host_logic import StubParser
+    z, meta = fu.load(name)
+    N, Nv, T, L, B, steps = meta["N"], meta["Nv"], meta["T"], meta["L"], meta["B"], meta["steps"]
+    tr = fu.make_data(meta["schema"], N=N, T=T, K=L, seed=meta["seed"], mask_kind="bern")
+    va = fu.make_data(meta["schema"], N=Nv, T=T, K=L, seed=meta["seed"] + 100, mask_kind="bern")
+    dd = dict(parser=StubParser(meta["schema"]),
+              response_train=torch.from_numpy(tr["response"]), cond_train=torch.from_numpy(tr["cond"]),
+              target_mask_train=torch.from_numpy(tr["mask"]).int(),             # int32 masks as dataprovider_pypots emits
+              response_val=torch.from_numpy(va["response"]), cond_val=torch.from_numpy(va["cond"]),
+              target_mask_val=torch.from_numpy(va["mask"]).int())
+    random.seed(meta["seed"])
+    torch.manual_seed(meta["seed"])
+    ae, latent, output, hist = getattr(VAE, fn)(None, 1, meta["H"], 2, meta["lr"], meta["wd"], steps, B, 1, meta["min_beta"],
+                                                meta["max_beta"], meta["E"], 8, L, "cuda", dd, noise_source="reference")
+    assert np.max(np.abs(np.array(hist["train"]) - z["train"]) / np.abs(z["train"])) < 1e-3
+    assert np.max(np.abs(np.array(hist["val"]) - z["val"]) / np.abs(z["val"])) < 1e-3
+    assert fu.rel_err(latent.cpu().numpy(), z["latent"]) < 2e-3
+    assert set(output.keys()) == {"bins", "cats", "nums"} and not latent.requires_grad
+    ws = fu.sub(z, "ws")
+    sd = ae.state_dict()
+    for k in ws:
+        assert abs(fu.stats(sd[k].cpu().numpy())[1] - ws[k][1]) < 1e-3 * max(ws[k][1], 1e-6), k
+
+
+# ------------------------------------------------------------------ properties at benchmark size
+def test_denoiser_fullsize_properties(dev):
+    """energy-like shape at the benchmark batch (B=4096, T=24, H=200, bf16): rows are
+    independent (a sub-batch reproduces its rows of the big batch) and the gradient is
+    additive over batch halves under the same global denominator."""
+    from timeautodiff_amd import DIFF
+    s = dict(n_bins=0, n_cats=1, n_nums=27, cards=[8])
+    sch = Schema(0, 1, 27, [8])
+    B, T, K, H = 4096, 24, 6, 200
+    data = fu.make_data(s, N=B, T=T, K=K, seed=1, mask_kind="ones")
+    data["cond"] = data["data"]
+    torch.manual_seed(5)
+    m = DIFF.BiRNN_score(K, 28, H, 2, 100, 8, 128, 0, 1, 27, [8])
+    m.set_compute_dtype("bf16")
+    eng = m.engine(dev)
+    g = torch.Generator().manual_seed(6)
+    t = torch.rand(B, T, 1, generator=g).sort(1)[0].to(dev)
+    i_idx = torch.randint(0, 100, (B,), generator=g).to(dev, torch.int32)
+    noise = torch.randn(B, T, K, generator=g).to(dev)
+    x0, ti, cond = T_(data["latent"], dev), T_(data["time_info"], dev), T_(data["cond"], dev)
+    al = DIFF.alphas.to(dev)
+    n_glob = B * T * K
+
+    def run(lo, hi):
+        eng.fp.zero_grad()
+        ls = torch.zeros(1, device=dev)
+        pred = eng.loss_and_grads(x0[lo:hi].contiguous(), t[lo:hi].contiguous(), i_idx[lo:hi].contiguous(),
+                                  noise[lo:hi].contiguous(), ti[lo:hi].contiguous(), cond[lo:hi].contiguous(), al, ls,
+                                  global_numel=n_glob)
+        return pred.clone(), ls.item(), eng.fp.gflat[:eng.fp.n_active].clone()
+    p_all, l_all, g_all = run(0, B)
+    p_a, l_a, g_a = run(0, B // 2)
+    p_b, l_b, g_b = run(B // 2, B)
+    assert torch.isfinite(p_all).all() and torch.isfinite(g_all).all()
+    assert torch.equal(p_all[:B // 2], p_a) and torch.equal(p_all[B // 2:], p_b)      # row independence, bit exact
+    assert abs(l_all - (l_a + l_b)) < 1e-5 * l_all
+    gs = g_a + g_b
+    assert float((g_all - gs).abs().max()) < 1e-3 * float(g_all.abs().max())           # atomics reorder sums only
+
+
+def test_sampler_fullsize_sharding_invariance(dev):
+    """1k-sequence generation: sampling a batch in two halves equals sampling it whole."""
+    from timeautodiff_amd import DIFF
+    s = dict(n_bins=0, n_cats=1, n_nums=27, cards=[8])
+    B, T, K, H = 1024, 24, 6, 200
+    data = fu.make_data(s, N=B, T=T, K=K, seed=2, mask_kind="ones")
+    torch.manual_seed(5)
+    m = DIFF.BiRNN_score(K, 28, H, 2, 100, 8, 128, 0, 1, 27, [8])
+    m.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(9)
+    noise = dict(x_T=torch.randn(B, T, K, generator=g), z=torch.randn(100, B, T, K, generator=g))
+    tgrid = torch.linspace(0, 1, T).view(1, -1, 1).repeat(B, 1, 1)
+    ti, cond = torch.from_numpy(data["time_info"]), torch.from_numpy(data["data"])
+    x = DIFF.sample(tgrid, B, T, K, 100, m, ti, cond, None, noise=noise)
+    h = B // 2
+    xa = DIFF.sample(tgrid[:h], h, T, K, 100, m, ti[:h], cond[:h], None, noise=dict(x_T=noise["x_T"][:h], z=noise["z"][:, :h]))
+    assert torch.isfinite(x).all()
+    assert torch.equal(x[:h], xa)

@@ -1,0 +1,474 @@
+"""Parity of every C-ABI kernel family against the numpy oracle on seeded inputs (GPU only).
+
+fp32 MFMA path: relative error <= 1e-4 (north-star tolerance; observed ~1e-6).
+bf16 MFMA path: compared against the oracle evaluated with both operands of every matrix
+product rounded to bf16 (the kernels' rounding points): GEMMs <= 1e-4, recurrences
+<= 5e-3 (an accumulation-order difference can flip a bf16 rounding of h)."""
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_util as fu
+from oracle import ops as oops
+from oracle import rnn as ornn
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-4
+BF16_EMU_TOL = 5e-3      # vs the oracle with operands rounded to bf16 at the kernels' rounding points
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops(lib):
+    from timeautodiff_amd import ops as _ops
+    return _ops
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).bfloat16().float().numpy()
+
+
+def D(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------ linear family
+SHAPES = [(5, 7, 3), (130, 70, 33), (257, 200, 6), (100, 800, 200), (64, 6, 400), (33, 100, 1), (300, 128, 448)]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_linear_fwd(ops, dev, prec, M, N, K):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K)
+    ldx, ldy = K + 3, N + 5
+    X = rnd(rng, M, ldx)
+    W = rnd(rng, N, K, scale=0.3)
+    b, b2 = rnd(rng, N), rnd(rng, N)
+    R = rnd(rng, M, N)
+    Xd, Wd, Yd = D(X, dev), D(W, dev), torch.zeros(M, ldy, device=dev)
+    Xr, Wr = (bf16_round(X[:, :K]), bf16_round(W)) if prec else (X[:, :K], W)
+    ref = Xr.astype(np.float64) @ Wr.astype(np.float64).T
+    # plain
+    ops.linear_fwd(prec, Xd[:, :K], Wd, None, Yd[:, :N])
+    assert fu.rel_err(Yd[:, :N].cpu().numpy(), ref) < F32_TOL
+    assert float(Yd[:, N:].abs().max()) == 0.0          # nothing written outside the slice
+    # bias + bias2 + residual + relu
+    ops.linear_fwd(prec, Xd[:, :K], Wd, D(b, dev), Yd[:, :N], act=ops.ACT_RELU, bias2=D(b2, dev), residual=D(R, dev))
+    assert fu.rel_err(Yd[:, :N].cpu().numpy(), np.maximum(ref + b + b2 + R, 0)) < F32_TOL
+    # accumulate into y
+    Yd.fill_(1.5)
+    ops.linear_fwd(prec, Xd[:, :K], Wd, None, Yd[:, :N], accumulate=True)
+    assert fu.rel_err(Yd[:, :N].cpu().numpy(), ref + 1.5) < F32_TOL
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_linear_bwd_data(ops, dev, prec, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    dY = rnd(rng, M, N)
+    W = rnd(rng, N, K, scale=0.3)
+    act = rnd(rng, M, K)
+    dYr, Wr = (bf16_round(dY), bf16_round(W)) if prec else (dY, W)
+    ref = dYr.astype(np.float64) @ Wr.astype(np.float64)
+    dX = torch.zeros(M, K + 2, device=dev)
+    ops.linear_bwd_data(prec, D(dY, dev), D(W, dev), dX[:, :K])
+    assert fu.rel_err(dX[:, :K].cpu().numpy(), ref) < F32_TOL
+    ops.linear_bwd_data(prec, D(dY, dev), D(W, dev), dX[:, :K], relu_of=D(act, dev))
+    assert fu.rel_err(dX[:, :K].cpu().numpy(), ref * (act > 0)) < F32_TOL
+    dX.fill_(2.0)
+    ops.linear_bwd_data(prec, D(dY, dev), D(W, dev), dX[:, :K], accumulate=True)
+    assert fu.rel_err(dX[:, :K].cpu().numpy(), ref + 2.0) < F32_TOL
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,N,K", SHAPES + [(4096, 96, 40)])
+def test_linear_bwd_weight(ops, dev, prec, M, N, K):
+    rng = np.random.default_rng(M + 7 * N + K)
+    dY = rnd(rng, M, N)
+    X = rnd(rng, M, K)
+    dYr, Xr = (bf16_round(dY), bf16_round(X)) if prec else (dY, X)
+    ref = dYr.astype(np.float64).T @ Xr.astype(np.float64)
+    dW = torch.full((N, K), 0.25, device=dev)
+    ops.linear_bwd_weight(prec, D(dY, dev), D(X, dev), dW)
+    assert fu.rel_err(dW.cpu().numpy(), ref + 0.25) < F32_TOL
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("shift", [-1, 1])
+def test_linear_bwd_weight_timeshift(ops, dev, prec, shift):
+    rng = np.random.default_rng(5)
+    B, T, N, K = 7, 6, 72, 24
+    dY = rnd(rng, B, T, N)
+    X = rnd(rng, B, T, K)
+    Xs = np.zeros_like(X)
+    if shift == -1:
+        Xs[:, 1:] = X[:, :-1]
+    else:
+        Xs[:, :-1] = X[:, 1:]
+    dYr, Xr = (bf16_round(dY), bf16_round(Xs)) if prec else (dY, Xs)
+    ref = dYr.reshape(B * T, N).astype(np.float64).T @ Xr.reshape(B * T, K).astype(np.float64)
+    dW = torch.zeros(N, K, device=dev)
+    ops.linear_bwd_weight(prec, D(dY, dev).view(B * T, N), D(X, dev).view(B * T, K), dW, T=T, tshift=shift)
+    assert fu.rel_err(dW.cpu().numpy(), ref) < F32_TOL
+
+
+def test_colsum(ops, dev):
+    rng = np.random.default_rng(9)
+    M, N = 1000, 150
+    dY = rnd(rng, M, N + 4)
+    s = rnd(rng, M)
+    o1 = torch.zeros(N, device=dev)
+    o2 = torch.ones(N, device=dev)
+    ow = torch.zeros(N, device=dev)
+    ops.colsum(D(dY, dev)[:, :N], out_sum=o1, out_sum2=o2, row_scale=D(s, dev), scale_mul=0.01, out_wsum=ow)
+    ref = dY[:, :N].astype(np.float64).sum(0)
+    assert fu.rel_err(o1.cpu().numpy(), ref) < F32_TOL
+    assert fu.rel_err(o2.cpu().numpy(), ref + 1) < F32_TOL
+    assert fu.rel_err(ow.cpu().numpy(), (dY[:, :N].astype(np.float64) * s[:, None]).sum(0) * 0.01) < F32_TOL
+
+
+# ------------------------------------------------------------------ recurrent family
+def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng):
+    """Runs fwd+bwd of one layer with len(rev_flags) directions; returns device results and oracle results."""
+    kind = "lstm" if cell == 0 else "gru"
+    G = 4 if cell == 0 else 3
+    S = 5 if cell == 0 else 4
+    nd = len(rev_flags)
+    IN = 11
+    x = rnd(rng, B, T, IN)
+    out = torch.zeros(B * T, nd * H, device=dev)
+    xproj = torch.zeros(B * T, nd * G * H, device=dev)
+    stash = torch.zeros(nd, B * T, S * H, device=dev)
+    dg = torch.zeros(B * T, nd * G * H, device=dev)
+    dgh = torch.zeros(B * T, nd * G * H, device=dev) if cell == 1 else None
+    dout = rnd(rng, B, T, nd * H)
+    nbytes = ops.rnn_packed_bytes(prec, H, G)
+    fdirs, bdirs, oracle = [], [], []
+    keep = []
+    for d, rev in enumerate(rev_flags):
+        k = 1.0 / np.sqrt(H)
+        Wih = (rng.uniform(-k, k, (G * H, IN))).astype(np.float32)
+        Whh = (rng.uniform(-k, k, (G * H, H))).astype(np.float32)
+        bih = (rng.uniform(-k, k, G * H)).astype(np.float32)
+        bhh = (rng.uniform(-k, k, G * H)).astype(np.float32)
+        fwd, bwd = (ornn.lstm_dir_fwd, ornn.lstm_dir_bwd) if cell == 0 else (ornn.gru_dir_fwd, ornn.gru_dir_bwd)
+        with (oops.bf16_operands() if prec else contextlib.nullcontext()):
+            hs, cache = fwd(x.astype(np.float64), Wih.astype(np.float64), Whh.astype(np.float64), bih.astype(np.float64),
+                            bhh.astype(np.float64), rev)
+            dx, dWih, dWhh, dbih, dbhh = bwd(Wih.astype(np.float64), Whh.astype(np.float64), cache,
+                                             dout[..., d * H:(d + 1) * H].astype(np.float64))
+        oracle.append(dict(hs=hs, cache=cache, dWih=dWih, dWhh=dWhh, dbih=dbih, dbhh=dbhh, dx=dx, Wih=Wih))
+        # device: input projection through the GEMM entry point in the same precision
+        Wd, Whd = D(Wih, dev), D(Whh, dev)
+        ops.linear_fwd(prec, D(x, dev).view(B * T, IN), Wd, D(bih, dev), xproj[:, d * G * H:(d + 1) * G * H],
+                       bias2=D(bhh, dev) if cell == 0 else None)
+        pf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        pb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ops.rnn_pack_weights(prec, H, G, Whd, pf, pb)
+        bh = D(bhh, dev)
+        keep += [Wd, Whd, pf, pb, bh]
+        fdirs.append(dict(xproj=xproj[:, d * G * H:(d + 1) * G * H], w_packed=pf, b_hh=bh if cell == 1 else None,
+                          out=out[:, d * H:(d + 1) * H], stash=stash[d], reverse=rev))
+        bdirs.append(dict(dout=D(dout, dev).view(B * T, nd * H)[:, d * H:(d + 1) * H], stash=stash[d],
+                          out=out[:, d * H:(d + 1) * H], w_packed_t=pb, dgates=dg[:, d * G * H:(d + 1) * G * H],
+                          dgates_h=dgh[:, d * G * H:(d + 1) * G * H] if dgh is not None else None, reverse=rev))
+    ops.rnn_fwd(cell, prec, B, T, H, fdirs)
+    ops.rnn_bwd(cell, prec, B, T, H, bdirs)
+    torch.cuda.synchronize()
+    return dict(out=out.cpu().numpy(), stash=stash.cpu().numpy(), dg=dg.cpu().numpy(),
+                dgh=dgh.cpu().numpy() if dgh is not None else None, oracle=oracle, x=x, dout=dout, kind=kind, G=G, S=S)
+
+
+RNN_CASES = [(5, 6, 24), (37, 5, 40), (70, 4, 200), (33, 3, 272)]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("cell", [0, 1])
+@pytest.mark.parametrize("B,T,H", RNN_CASES)
+def test_rnn_fwd_bwd(ops, dev, cell, prec, B, T, H):
+    rng = np.random.default_rng(100 * cell + 10 * prec + H)
+    r = _run_rnn(ops, dev, cell, prec, B, T, H, [False, True], rng)
+    tol = F32_TOL if prec == 0 else BF16_EMU_TOL
+    G, S = r["G"], r["S"]
+    mm = oops.mm
+    ctx = oops.bf16_operands() if prec else contextlib.nullcontext()
+    with ctx:
+      for d, o in enumerate(r["oracle"]):
+        hs = o["hs"].reshape(B * T, H)
+        assert fu.rel_err(r["out"][:, d * H:(d + 1) * H], hs) < tol, ("h", d)
+        cache = o["cache"]
+        if cell == 0:
+            _, _, cs, gates, _ = cache
+            ref_stash = np.concatenate([gates.reshape(B * T, 4 * H), cs.reshape(B * T, H)], 1)
+        else:
+            ref_stash = cache[2].reshape(B * T, 4 * H)
+        assert fu.rel_err(r["stash"][d], ref_stash) < tol, ("stash", d)
+        # pre-activation gradients: compare through the weight gradients they imply (what the model uses)
+        dgd = r["dg"][:, d * G * H:(d + 1) * G * H].astype(np.float64)
+        dWih = mm(dgd.T, r["x"].reshape(B * T, -1).astype(np.float64))
+        assert fu.rel_err(dWih, o["dWih"]) < 4 * tol, ("dWih", d)
+        assert fu.rel_err(dgd.sum(0), o["dbih"]) < 4 * tol, ("dbih", d)
+        if cell == 1:
+            dghd = r["dgh"][:, d * G * H:(d + 1) * G * H].astype(np.float64)
+            assert fu.rel_err(dghd.sum(0), o["dbhh"]) < 4 * tol, ("dbhh", d)
+        dx = mm(dgd, o["Wih"].astype(np.float64))
+        assert fu.rel_err(dx, o["dx"].reshape(B * T, -1)) < 4 * tol, ("dx", d)
+
+
+def test_rnn_bwd_phased_path(ops, dev):
+    """fp32 LSTM with H = 320: the gate-gradient tile exceeds LDS and the backward kernel
+    stages it gate by gate."""
+    rng = np.random.default_rng(77)
+    B, T, H = 9, 3, 320
+    r = _run_rnn(ops, dev, 0, 0, B, T, H, [False], rng)
+    o = r["oracle"][0]
+    assert fu.rel_err(r["out"], o["hs"].reshape(B * T, H)) < F32_TOL
+    dgd = r["dg"].astype(np.float64)
+    assert fu.rel_err(dgd.T @ r["x"].reshape(B * T, -1).astype(np.float64), o["dWih"]) < F32_TOL
+    assert fu.rel_err(dgd @ o["Wih"].astype(np.float64), o["dx"].reshape(B * T, -1)) < F32_TOL
+
+
+def test_rnn_inference_matches_training(ops, dev):
+    """stash = NULL (inference) produces the same h as the training launch."""
+    rng = np.random.default_rng(3)
+    B, T, H, G = 17, 5, 40, 4
+    xproj = D(rnd(rng, B * T, G * H), dev)
+    Whh = D(rnd(rng, G * H, H, scale=0.2), dev)
+    nbytes = ops.rnn_packed_bytes(0, H, G)
+    pf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ops.rnn_pack_weights(0, H, G, Whh, pf, None)
+    o1 = torch.zeros(B * T, H, device=dev)
+    o2 = torch.zeros(B * T, H, device=dev)
+    st = torch.zeros(B * T, 5 * H, device=dev)
+    ops.rnn_fwd(0, 0, B, T, H, [dict(xproj=xproj, w_packed=pf, out=o1, stash=st, reverse=False)])
+    ops.rnn_fwd(0, 0, B, T, H, [dict(xproj=xproj, w_packed=pf, out=o2, stash=None, reverse=False)])
+    assert torch.equal(o1, o2)
+
+
+# ------------------------------------------------------------------ elementwise family
+def test_add_noise_and_loss(ops, dev):
+    rng = np.random.default_rng(1)
+    B, T, K = 9, 7, 6
+    x0, noise = rnd(rng, B, T, K), rnd(rng, B, T, K)
+    i_idx = rng.integers(0, 100, B).astype(np.int32)
+    _, alphas = oops.schedule(100)
+    xn = torch.zeros(B, T, K, device=dev)
+    i_f = torch.zeros(B, T, device=dev)
+    ops.add_noise(D(x0, dev), D(noise, dev), D(i_idx, dev), D(alphas, dev), xn, i_f)
+    assert fu.rel_err(xn.cpu().numpy(), oops.add_noise(x0, i_idx, noise, alphas)) < 1e-6
+    assert np.array_equal(i_f.cpu().numpy(), np.repeat(i_idx[:, None], T, 1).astype(np.float32))
+    pred = rnd(rng, B, T, K)
+    dp = torch.zeros(B, T, K, device=dev)
+    ls = torch.zeros(1, device=dev)
+    ops.mse_loss(D(pred, dev), D(noise, dev), 2.0 / pred.size, dp, ls)
+    assert abs(ls.item() - float(((pred - noise).astype(np.float64) ** 2).sum())) < 1e-5 * ls.item()
+    assert fu.rel_err(dp.cpu().numpy(), 2.0 / pred.size * (pred - noise)) < 1e-6
+
+
+def test_sampler_update(ops, dev):
+    rng = np.random.default_rng(2)
+    x, pred, z = rnd(rng, 4, 5, 6), rnd(rng, 4, 5, 6), rnd(rng, 4, 5, 6)
+    betas, alphas = oops.schedule(100)
+    for s, last in ((57, False), (0, True)):
+        b, a = np.float32(betas[s]), np.float32(alphas[s])
+        xd = D(x, dev)
+        ops.sampler_update(xd, D(pred, dev), D(z, dev), 1 / np.sqrt(1 - b), b / np.sqrt(1 - a), np.sqrt(b), last)
+        assert fu.rel_err(xd.cpu().numpy(), oops.sampler_update(x, pred, z, b, a, last)) < 1e-6
+
+
+def test_sincos_embed_posenc_silu(ops, dev):
+    rng = np.random.default_rng(4)
+    rows, nn_, nd, E = 50, 5, 3, 16
+    cards = [2, 7, 1]
+    x = np.concatenate([np.stack([rng.integers(0, c, rows) for c in cards], 1).astype(np.float32),
+                        rng.random((rows, nn_), dtype=np.float32)], 1)
+    xd = D(x, dev)
+    out = torch.zeros(rows, 16 * nn_, device=dev)
+    ops.sincos_features(xd[:, nd:], out)
+    assert np.max(np.abs(out.cpu().numpy() - oops.sincos_features(x[:, nd:]))) < 2e-6
+    tables = rnd(rng, sum(cards), E)
+    off = [0, 2, 9]
+    eo = torch.zeros(rows, nd * E + 3, device=dev)
+    ops.embed_fwd(xd[:, :nd], D(tables, dev), off, cards, E, eo[:, :nd * E])
+    ref = np.concatenate([tables[off[d] + x[:, d].astype(int)] for d in range(nd)], 1)
+    assert np.array_equal(eo[:, :nd * E].cpu().numpy(), ref)
+    dout = rnd(rng, rows, nd * E)
+    dt = torch.zeros(sum(cards), E, device=dev)
+    ops.embed_bwd(xd[:, :nd], D(dout, dev), dt, off, cards, E)
+    gref = np.zeros_like(tables, dtype=np.float64)
+    for d in range(nd):
+        np.add.at(gref, off[d] + x[:, d].astype(int), dout[:, d * E:(d + 1) * E])
+    assert fu.rel_err(dt.cpu().numpy(), gref) < 1e-5
+    # positional encodings (t_enc: max 1; i_enc: max 100)
+    H = 24
+    for mx, tv in ((1.0, rng.random(rows, dtype=np.float32)), (100.0, rng.integers(0, 100, rows).astype(np.float32))):
+        sc, sh = oops.posenc_tables(H, mx)
+        w, b = rnd(rng, H // 2, 1), rnd(rng, H // 2)
+        po = torch.zeros(rows, H, device=dev)
+        ops.posenc_fwd(D(tv, dev), 1, rows, H, 1.0 / mx, D(w, dev), D(b, dev), D(sc, dev), D(sh, dev), po)
+        assert np.max(np.abs(po.cpu().numpy() - oops.posenc_fwd(tv[:, None], w, b, mx, sc, sh))) < 1e-5
+    zt = rnd(rng, 40, 33)
+    a = torch.zeros(40, 33, device=dev)
+    ops.silu_fwd(D(zt, dev), a)
+    assert fu.rel_err(a.cpu().numpy(), oops.silu(zt.astype(np.float64))) < 1e-6
+    da = rnd(rng, 40, 33)
+    dz = torch.zeros(40, 33, device=dev)
+    ops.silu_bwd(D(zt, dev), D(da, dev), dz)
+    assert fu.rel_err(dz.cpu().numpy(), da * oops.silu_grad(zt.astype(np.float64))) < 1e-6
+
+
+@pytest.mark.parametrize("Dn", [48, 400, 1024])
+def test_layernorm(ops, dev, Dn):
+    rng = np.random.default_rng(Dn)
+    rows = 77
+    x, dy = rnd(rng, rows, Dn), rnd(rng, rows, Dn)
+    g, b = rnd(rng, Dn), rnd(rng, Dn)
+    y = torch.zeros(rows, Dn, device=dev)
+    mr = torch.zeros(rows, 2, device=dev)
+    ops.layernorm_fwd(D(x, dev), D(g, dev), D(b, dev), y, mr)
+    yr, cache = oops.layernorm_fwd(x.astype(np.float64), g, b)
+    assert fu.rel_err(y.cpu().numpy(), yr) < 1e-5
+    dx = torch.zeros(rows, Dn, device=dev)
+    dg = torch.zeros(Dn, device=dev)
+    db = torch.zeros(Dn, device=dev)
+    ops.layernorm_bwd(D(dy, dev), D(x, dev), D(g, dev), mr, dx, dg, db)
+    dxr, dgr, dbr = oops.layernorm_bwd(dy.astype(np.float64), g.astype(np.float64), cache)
+    assert fu.rel_err(dx.cpu().numpy(), dxr) < 1e-5
+    assert fu.rel_err(dg.cpu().numpy(), dgr) < 1e-5
+    assert fu.rel_err(db.cpu().numpy(), dbr) < 1e-5
+
+
+def test_gather_and_adam(ops, dev):
+    from oracle.optim import Adam
+    rng = np.random.default_rng(6)
+    src = rnd(rng, 20, 4, 3)
+    idx = rng.permutation(20)[:7].astype(np.int64)
+    out = torch.zeros(7, 4, 3, device=dev)
+    ops.gather_rows(D(src, dev), D(idx, dev), out)
+    assert np.array_equal(out.cpu().numpy(), src[idx])
+    n = 1000
+    p = rnd(rng, n)
+    pd = D(p.copy(), dev)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    sd = {"p": p.copy()}
+    opt = Adam(sd, lr=2e-4, weight_decay=1e-6)
+    for step in range(1, 4):
+        g = rnd(rng, n)
+        ops.adam_step(pd, D(g, dev), m, v, 2e-4, 0.9, 0.999, 1e-8, 1e-6, step)
+        opt.step({"p": g})
+    assert fu.rel_err(pd.cpu().numpy() - p, sd["p"] - p) < 1e-4      # the UPDATE agrees, not just the value
+
+
+# ------------------------------------------------------------------ VAE family
+def test_vae_reparam(ops, dev):
+    rng = np.random.default_rng(8)
+    n = 500
+    mu, lv, eps, dz = rnd(rng, n), rnd(rng, n, scale=0.5), rnd(rng, n), rnd(rng, n)
+    z = torch.zeros(n, device=dev)
+    ks = torch.zeros(1, device=dev)
+    ops.vae_reparam_fwd(D(mu, dev), D(lv, dev), D(eps, dev), z, ks)
+    assert fu.rel_err(z.cpu().numpy(), mu + eps * np.exp(0.5 * lv)) < 1e-6
+    ref = float((1 + lv.astype(np.float64) - mu.astype(np.float64) ** 2 - np.exp(lv.astype(np.float64))).sum())
+    assert abs(ks.item() - ref) < 1e-4 * abs(ref)
+    dmu = torch.zeros(n, device=dev)
+    dlv = torch.zeros(n, device=dev)
+    ops.vae_reparam_bwd(D(dz, dev), D(mu, dev), D(lv, dev), D(eps, dev), 0.3, dmu, dlv)
+    assert fu.rel_err(dmu.cpu().numpy(), dz + 0.3 * mu) < 1e-6
+    assert fu.rel_err(dlv.cpu().numpy(), dz * eps * 0.5 * np.exp(0.5 * lv) - 0.15 * (1 - np.exp(lv))) < 1e-5
+
+
+@pytest.mark.parametrize("schema", ["numeric", "mixed", "metro"])
+def test_vae_heads_loss(ops, dev, schema):
+    from oracle import vae as ovae
+    from oracle.denoiser import Schema
+    s = fu.SCHEMAS[schema]
+    sch = Schema(s["n_bins"], s["n_cats"], s["n_nums"], list(s["cards"]))
+    rng = np.random.default_rng(12)
+    B, T = 6, 5
+    rows = B * T
+    data = fu.make_data(s, N=B, T=T, K=4, seed=5, mask_kind="bern")
+    F = data["data"].shape[-1]
+    NH = sch.n_bins + sum(sch.cards) + sch.n_nums
+    raw = rnd(rng, rows, NH)
+    mask = data["mask"].reshape(rows, F)
+    target = (data["data"] * data["mask"]).reshape(rows, F)
+    # oracle: rebuild the head outputs from the raw pre-activations
+    out = {}
+    o = 0
+    if sch.n_bins:
+        out["bins"] = (raw[:, o:o + sch.n_bins] + np.where(mask[:, :sch.n_bins] == 0, -100.0, 0.0)).reshape(B, T, -1)
+        o += sch.n_bins
+    if sch.n_cats:
+        out["cats"] = []
+        for j, c in enumerate(sch.cards):
+            lg = raw[:, o:o + c].copy()
+            lg[:, 0] += np.where(mask[:, sch.n_bins + j] == 0, 100.0, 0.0)
+            out["cats"].append(lg.reshape(B, T, c))
+            o += c
+    sig = None
+    if sch.n_nums:
+        sig = oops.sigmoid(raw[:, o:o + sch.n_nums].astype(np.float64))
+        mn = mask[:, sch.n_bins + sch.n_cats:]
+        out["nums"] = (sig * mn).reshape(B, T, -1)
+    mu = np.zeros((B, T, 2), np.float32)
+    total, parts, d = ovae.loss_fwd(out, target.reshape(B, T, F), mu, mu, 0.0, sch)
+    heads = D(raw, dev)
+    dh = torch.zeros(rows, NH, device=dev)
+    lp = torch.zeros(2 + max(sch.n_cats, 1), device=dev)
+    s_bce = 1.0 / (rows * sch.n_bins) if sch.n_bins else 0.0
+    s_ce = 1.0 / (rows * sch.n_cats) if sch.n_cats else 0.0
+    s_mse = 2.0 / (rows * sch.n_nums) if sch.n_nums else 0.0
+    ops.vae_heads_loss(heads, D(mask, dev), D(target, dev), sch.n_bins, sch.n_cats, sch.n_nums, sch.cards, s_bce, s_ce, s_mse, dh, lp)
+    h = heads.cpu().numpy()
+    g = dh.cpu().numpy()
+    p = lp.cpu().numpy().astype(np.float64)
+    o = 0
+    if sch.n_bins:
+        assert fu.rel_err(h[:, o:o + sch.n_bins], out["bins"].reshape(rows, -1)) < 1e-6
+        assert fu.rel_err(g[:, o:o + sch.n_bins], d["bins"].reshape(rows, -1)) < 1e-5
+        assert abs(p[0] / (rows * sch.n_bins) - parts["bce"]) < 1e-5 * max(parts["bce"], 1e-9)
+        o += sch.n_bins
+    for j, c in enumerate(sch.cards if sch.n_cats else []):
+        assert fu.rel_err(h[:, o:o + c], out["cats"][j].reshape(rows, c)) < 1e-6
+        assert np.max(np.abs(g[:, o:o + c] - d["cats"][j].reshape(rows, c))) < 1e-5 * max(np.max(np.abs(d["cats"][j])), 1e-3)
+        o += c
+    if sch.n_cats:
+        assert abs(p[2:2 + sch.n_cats].sum() / (rows * sch.n_cats) - parts["ce"]) < 1e-5 * max(parts["ce"], 1e-9)
+    if sch.n_nums:
+        assert fu.rel_err(h[:, o:], out["nums"].reshape(rows, -1)) < 1e-6
+        mn = mask[:, sch.n_bins + sch.n_cats:]
+        assert fu.rel_err(g[:, o:], d["nums"].reshape(rows, -1) * mn * sig * (1 - sig)) < 1e-5
+        assert abs(p[1] / (rows * sch.n_nums) - parts["mse"]) < 1e-5 * max(parts["mse"], 1e-9)
+
+
+def test_vae_prepare(ops, dev):
+    rng = np.random.default_rng(13)
+    a, b = rnd(rng, 100), rnd(rng, 100)
+    m = (rng.random(100) < 0.5).astype(np.float32)
+    inp = torch.zeros(100, device=dev)
+    tgt = torch.zeros(100, device=dev)
+    ops.vae_prepare(D(a, dev), D(b, dev), D(m, dev), inp, tgt)
+    assert np.array_equal(inp.cpu().numpy(), a + b)
+    assert np.array_equal(tgt.cpu().numpy(), (a + b) * m)
+
+
+def test_bad_arguments_fail_loudly(ops, dev):
+    from timeautodiff_amd._lib import TadError
+    x = torch.zeros(4, 4, device=dev)
+    with pytest.raises(TadError):
+        ops.rnn_fwd(0, 0, 4, 1, 2000, [dict(xproj=x, w_packed=x, out=x, stash=None, reverse=False)])   # H too large
+    with pytest.raises(TadError):
+        ops.linear_fwd(0, torch.zeros(4, 4), x, None, x)                                                  # host tensor

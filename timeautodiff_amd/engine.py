@@ -254,7 +254,7 @@ class RnnStack:
                                       fp.g(self.name("weight_hh", layer, d)), T=T, tshift=(1 if self.rev[d] else -1))
             # gradient wrt the layer input
             if layer > 0 or need_dx:
-                dx = ws.get(f"{tag}.dx{layer}", (BT, in_l))
+                dx = ws.get(f"{tag}.dx{layer}", (BT, in_l if shared else nd * H))
                 ro = relu_of if layer == 0 else None
                 if shared:
                     ops.linear_bwd_data(prec, dg, fp.pgroup(self.name("weight_ih", layer, 0), nd * GH, in_l), dx, relu_of=ro)
