@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtad_hip.so")
+LIB_PATH = os.environ.get("TAD_HIP_LIB") or os.path.join(_HERE, "libtad_hip.so")   # override: A/B builds of the same ABI
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1

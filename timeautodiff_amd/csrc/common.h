@@ -37,6 +37,10 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // device math
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate nonlinearities on the hardware exp2 / reciprocal units (v_exp_f32, v_rcp_f32):
+// absolute error ~2e-7, saturating correctly at both ends.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // Row of a 32x32 MFMA accumulator register: C/D layout of v_mfma_f32_32x32x*:
 // column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).

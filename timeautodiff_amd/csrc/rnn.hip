@@ -124,7 +124,7 @@ __device__ __forceinline__ void lds_put(unsigned char* base, int lds_ld, int row
 // ---------------------------------------------------------------------------
 struct RnnFwdArgs {
   tad_rnn_dir_t d[MAXDIR];
-  int B, T, H, NJ, nk, lds_ld;
+  int B, T, H, NJ, nk, lds_ld, rpw;
 };
 
 template <int CELL, bool BF16, int JPW>
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
   const tad_rnn_dir_t d = a.d[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int col = lane & 31;
-  const int64_t b0 = (int64_t)blockIdx.x * 32;
+  const int64_t b0 = (int64_t)blockIdx.x * a.rpw;   // rows >= rpw of the 32-row MFMA tile stay empty
   const size_t buf_bytes = (size_t)32 * a.lds_ld * ESZ;
   const int H = a.H, T = a.T;
   const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed);
@@ -158,6 +158,42 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
   }
   __syncthreads();
 
+  // Addressing: row r of the tile is batch b0 + cr + 4*half with cr = (r&3) + 8*(r>>2) a
+  // compile-time constant, so every access is (wave-uniform row base) + (one 32-bit per-lane
+  // offset shared by all 16 rows); lanes 0-31 / 32-63 each cover one full 128-byte line.
+  const int half = lane >> 5;
+  // input-side pre-activations of one step for chunk slot jj (the accumulator seeds)
+  auto load_xp = [&](int step_, int jj, f32x16* acc, float* xn) {
+    const int tt_ = d.reverse ? T - 1 - step_ : step_;
+    const int u = 32 * (wave + jj * nw) + col;
+    const bool uok = u < H;
+    const int voff = (4 * half * T + tt_) * (int)d.ld_xproj + u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cr = (r & 3) + 8 * (r >> 2);
+      const bool ok = uok && (cr + 4 * half) < a.rpw && (b0 + cr + 4 * half) < a.B;
+      const float* xp = d.xproj + (b0 + cr) * (int64_t)T * d.ld_xproj;
+      if constexpr (CELL == TAD_CELL_LSTM) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g][r] = ok ? xp[voff + g * H] : 0.f;
+      } else {
+        acc[0][r] = ok ? xp[voff] : 0.f;            // b_hh is added in the epilogue so that the
+        acc[1][r] = ok ? xp[voff + H] : 0.f;        // prefetched values stay untouched (in flight)
+        acc[2][r] = 0.f;
+        xn[r] = ok ? xp[voff + 2 * H] : 0.f;
+      }
+    }
+  };
+
+  // With one chunk per wave the next step's xproj is fetched right after this step's MFMAs,
+  // so its HBM latency hides under the gate math, the stores and the barrier.
+  constexpr bool PREFETCH = (JPW == 1);
+  f32x16 nacc[G];
+  float nxn[16];
+  if constexpr (PREFETCH) {
+    if (wave < a.NJ) load_xp(0, 0, nacc, nxn);
+  }
+
   for (int step = 0; step < T; ++step) {
     const int tt = d.reverse ? T - 1 - step : step;
     const unsigned char* cur = smem + (size_t)(step & 1) * buf_bytes;
@@ -170,40 +206,38 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
         const bool uok = u < H;
         f32x16 acc[G];
         float xn[16];
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t b = b0 + acc_row32(r, lane);
-          const bool ok = uok && b < a.B;
-          const float* xp = d.xproj + (b * T + tt) * d.ld_xproj + u;
-          if constexpr (CELL == TAD_CELL_LSTM) {
+          for (int g = 0; g < G; ++g) acc[g] = nacc[g];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g][r] = ok ? xp[(int64_t)g * H] : 0.f;
-          } else {
-            acc[0][r] = ok ? xp[0] + bh[jj][0] : 0.f;
-            acc[1][r] = ok ? xp[H] + bh[jj][1] : 0.f;
-            acc[2][r] = ok ? bh[jj][2] : 0.f;
-            xn[r] = ok ? xp[2 * (int64_t)H] : 0.f;
-          }
+          for (int r = 0; r < 16; ++r) xn[r] = nxn[r];
+        } else {
+          load_xp(step, jj, acc, xn);
         }
         mma_stream<BF16, G, PF>(acc, cur, a.lds_ld, wp + (int64_t)j * a.nk * G * 64, a.nk, lane);
+        if constexpr (PREFETCH) {
+          if (step + 1 < T) load_xp(step + 1, 0, nacc, nxn);
+        }
+        const int ooff = (4 * half * T + tt) * (int)d.ld_out + u;
+        const int soff = (4 * half * T + tt) * (S * H) + u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = acc_row32(r, lane);
-          const int64_t b = b0 + row;
-          const bool ok = uok && b < a.B;
+          const int cr = (r & 3) + 8 * (r >> 2);
+          const int row = cr + 4 * half;
+          const bool ok = uok && row < a.rpw && (b0 + row) < a.B;
           float h;
           float sv[S];
           if constexpr (CELL == TAD_CELL_LSTM) {
-            const float ig = sigmoid_acc(acc[0][r]), fg = sigmoid_acc(acc[1][r]);
-            const float gg = tanhf(acc[2][r]), og = sigmoid_acc(acc[3][r]);
+            const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
+            const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
             const float c = fg * st[jj][r] + ig * gg;
             st[jj][r] = c;
-            h = og * tanhf(c);
+            h = og * fast_tanh(c);
             sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og; sv[4] = c;
           } else {
-            const float rg = sigmoid_acc(acc[0][r]), zg = sigmoid_acc(acc[1][r]);
-            const float hpn = acc[2][r];
-            const float ng = tanhf(xn[r] + rg * hpn);
+            const float rg = fast_sigmoid(acc[0][r] + bh[jj][0]), zg = fast_sigmoid(acc[1][r] + bh[jj][1]);
+            const float hpn = acc[2][r] + bh[jj][2];
+            const float ng = fast_tanh(xn[r] + rg * hpn);
             h = (1.f - zg) * ng + zg * st[jj][r];
             st[jj][r] = h;
             sv[0] = rg; sv[1] = zg; sv[2] = ng; sv[3] = hpn;
@@ -211,11 +245,11 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
           if (!ok) h = 0.f;
           lds_put<BF16>(nxt, a.lds_ld, row, u, h);
           if (ok) {
-            d.out[(b * T + tt) * d.ld_out + u] = h;
+            (d.out + (b0 + cr) * (int64_t)T * d.ld_out)[ooff] = h;
             if (d.stash) {
-              float* sp = d.stash + (b * T + tt) * (int64_t)(S * H) + u;
+              float* sp = d.stash + (b0 + cr) * (int64_t)T * (S * H);
 #pragma unroll
-              for (int q = 0; q < S; ++q) sp[(int64_t)q * H] = sv[q];
+              for (int q = 0; q < S; ++q) sp[soff + q * H] = sv[q];
             }
           }
         }
@@ -228,7 +262,7 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
 // ---------------------------------------------------------------------------
 struct RnnBwdArgs {
   tad_rnn_bwd_dir_t d[MAXDIR];
-  int B, T, H, NJ, width, lds_ld, nk_total, nk_gate;
+  int B, T, H, NJ, width, lds_ld, nk_total, nk_gate, rpw;
 };
 
 template <int CELL, bool BF16, int JPW, bool PHASED>
@@ -240,10 +274,11 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
   const tad_rnn_bwd_dir_t d = a.d[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int col = lane & 31;
-  const int64_t b0 = (int64_t)blockIdx.x * 32;
+  const int64_t b0 = (int64_t)blockIdx.x * a.rpw;   // rows >= rpw of the 32-row MFMA tile stay empty
   const int H = a.H, T = a.T;
   const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed_t);
   const float* dsrc = (CELL == TAD_CELL_GRU) ? d.dgates_h : d.dgates;   // operand of the recurrent product
+  const int half = lane >> 5;
 
   f32x16 acc[JPW];
   float dcs[JPW][16];
@@ -257,29 +292,36 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
     const int tt = d.reverse ? T - 1 - n : n;
     const int tprev = (n > 0) ? (d.reverse ? tt + 1 : tt - 1) : -1;
     // ---- phase 1: gate gradients for the owned (row, unit) elements
+    // (wave-uniform row bases + one 32-bit per-lane offset per buffer, as in the forward)
 #pragma unroll
     for (int jj = 0; jj < JPW; ++jj) {
       const int j = wave + jj * nw;
       if (j < a.NJ) {
         const int u = 32 * j + col;
         const bool uok = u < H;
+        const int rowT = 4 * half * T;
+        const int doff = (rowT + tt) * (int)d.ld_dout + u;
+        const int soff = (rowT + tt) * (S * H) + u;
+        const int spoff = (rowT + tprev) * (S * H) + u;
+        const int ooff = (rowT + tprev) * (int)d.ld_out + u;
+        const int goff = (rowT + tt) * (int)d.ld_dgates + u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = acc_row32(r, lane);
-          const int64_t b = b0 + row;
-          const bool ok = uok && b < a.B;
+          const int cr = (r & 3) + 8 * (r >> 2);
+          const int row = cr + 4 * half;
+          const bool ok = uok && row < a.rpw && (b0 + row) < a.B;
           float da[G];
           float nacc = 0.f;
 #pragma unroll
           for (int g = 0; g < G; ++g) da[g] = 0.f;
           if (ok) {
-            const int64_t bt = b * T + tt;
-            const float dh = d.dout[bt * d.ld_dout + u] + acc[jj][r];
-            const float* sp = d.stash + bt * (int64_t)(S * H) + u;
+            const int64_t rb = (b0 + cr) * (int64_t)T;
+            const float dh = (d.dout + rb * d.ld_dout)[doff] + acc[jj][r];
+            const float* sp = d.stash + rb * (S * H);
             if constexpr (CELL == TAD_CELL_LSTM) {
-              const float ig = sp[0], fg = sp[H], gg = sp[2 * (int64_t)H], og = sp[3 * (int64_t)H], c = sp[4 * (int64_t)H];
-              const float cprev = (tprev >= 0) ? d.stash[(b * T + tprev) * (int64_t)(S * H) + 4 * (int64_t)H + u] : 0.f;
-              const float tc = tanhf(c);
+              const float ig = sp[soff], fg = sp[soff + H], gg = sp[soff + 2 * H], og = sp[soff + 3 * H], c = sp[soff + 4 * H];
+              const float cprev = (tprev >= 0) ? sp[spoff + 4 * H] : 0.f;
+              const float tc = fast_tanh(c);
               const float dog = dh * tc;
               const float dc = dh * og * (1.f - tc * tc) + dcs[jj][r];
               dcs[jj][r] = dc * fg;
@@ -287,22 +329,22 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
               da[1] = dc * cprev * fg * (1.f - fg);
               da[2] = dc * ig * (1.f - gg * gg);
               da[3] = dog * og * (1.f - og);
-              float* dg = d.dgates + bt * d.ld_dgates + u;
+              float* dg = d.dgates + rb * d.ld_dgates;
 #pragma unroll
-              for (int g = 0; g < 4; ++g) dg[(int64_t)g * H] = da[g];
+              for (int g = 0; g < 4; ++g) dg[goff + g * H] = da[g];
             } else {
-              const float rg = sp[0], zg = sp[H], ng = sp[2 * (int64_t)H], hpn = sp[3 * (int64_t)H];
-              const float hprev = (tprev >= 0) ? d.out[(b * T + tprev) * d.ld_out + u] : 0.f;
+              const float rg = sp[soff], zg = sp[soff + H], ng = sp[soff + 2 * H], hpn = sp[soff + 3 * H];
+              const float hprev = (tprev >= 0) ? (d.out + rb * d.ld_out)[ooff] : 0.f;
               const float dn = dh * (1.f - zg);
               const float dz = dh * (hprev - ng);
               const float dan = dn * (1.f - ng * ng);
               const float dar = dan * hpn * rg * (1.f - rg);
               const float daz = dz * zg * (1.f - zg);
               da[0] = dar; da[1] = daz; da[2] = dan * rg;
-              float* dg = d.dgates + bt * d.ld_dgates + u;
-              dg[0] = dar; dg[H] = daz; dg[2 * (int64_t)H] = dan;
-              float* dgh = d.dgates_h + bt * d.ld_dgates + u;
-              dgh[0] = dar; dgh[H] = daz; dgh[2 * (int64_t)H] = da[2];
+              float* dg = d.dgates + rb * d.ld_dgates;
+              dg[goff] = dar; dg[goff + H] = daz; dg[goff + 2 * H] = dan;
+              float* dgh = d.dgates_h + rb * d.ld_dgates;
+              dgh[goff] = dar; dgh[goff + H] = daz; dgh[goff + 2 * H] = da[2];
               nacc = dh * zg;
             }
           }
@@ -335,7 +377,7 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
               const int row = acc_row32(r, lane);
               const int64_t b = b0 + row;
               float v = 0.f;
-              if (u < H && b < a.B) v = dsrc[(b * T + tt) * d.ld_dgates + (int64_t)g * H + u];
+              if (u < H && row < a.rpw && b < a.B) v = dsrc[(b * T + tt) * d.ld_dgates + (int64_t)g * H + u];
               lds_put<BF16>(smem, a.lds_ld, row, u, v);
             }
           }
@@ -359,6 +401,16 @@ struct Geom {
   int NJ, width, nkf, nkb, jpw, nw;
 };
 
+// Rows of the batch one workgroup owns.  The MFMA tile is 32 rows; when the batch is too
+// small to give every CU a workgroup, fewer real rows per workgroup spread the per-step
+// HBM traffic (xproj in, h / stash out) over more CUs -- the step time is bound by the
+// per-CU memory path, not by the matrix cores, in that regime.
+int rows_per_wg(int64_t B, int ndir) {
+  int rpw = 32;
+  while (rpw > 8 && cdiv64(B, rpw) * ndir < 256) rpw >>= 1;
+  return rpw;
+}
+
 Geom geom(int prec, int64_t H, int G) {
   Geom g;
   const int ks = ks_of(prec == TAD_BF16);
@@ -373,20 +425,24 @@ Geom geom(int prec, int64_t H, int G) {
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
+// raises the dynamic-LDS limit of a kernel; `configured` caches the largest size already set
 template <typename K>
-int set_lds(K kernel, size_t bytes) {
+int set_lds(K kernel, size_t bytes, size_t& configured) {
+  if (bytes <= configured) return TAD_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) {
     tad_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", bytes, hipGetErrorString(e));
     return TAD_ERR_LAUNCH;
   }
+  configured = bytes;
   return TAD_OK;
 }
 
 template <int CELL, bool BF16, int JPW>
 int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   auto k = rnn_fwd_kernel<CELL, BF16, JPW>;
-  if (int rc = set_lds(k, lds)) return rc;
+  static size_t configured = 0;
+  if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
@@ -395,7 +451,8 @@ int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream
 template <int CELL, bool BF16, int JPW, bool PHASED>
 int launch_bwd(const RnnBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   auto k = rnn_bwd_kernel<CELL, BF16, JPW, PHASED>;
-  if (int rc = set_lds(k, lds)) return rc;
+  static size_t configured = 0;
+  if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
@@ -444,12 +501,14 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int64_t B, int64_t T, int64_t H, 
     a.d[i] = dirs[i];
     TAD_CHECK(dirs[i].xproj && dirs[i].w_packed && dirs[i].out, "tad_rnn_fwd: null pointer in dir %d", i);
     TAD_CHECK(dirs[i].ld_xproj >= G * H && dirs[i].ld_out >= H, "tad_rnn_fwd: bad leading dimension in dir %d", i);
+    TAD_CHECK((5 * T + 1) * (dirs[i].ld_xproj + dirs[i].ld_out + 5 * H) < (int64_t)1 << 31, "tad_rnn_fwd: T * ld too large for 32-bit lane offsets");
   }
   a.B = (int)B; a.T = (int)T; a.H = (int)H; a.NJ = g.NJ; a.nk = g.nkf;
+  a.rpw = rows_per_wg(B, ndir);
   a.lds_ld = g.width + (bf ? 8 : 4);
   const size_t lds = (size_t)2 * 32 * a.lds_ld * (bf ? 2 : 4);
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_fwd: H=%ld needs %zu bytes of LDS in this precision (limit %zu)", (long)H, lds, LDS_LIMIT);
-  dim3 grid((unsigned)cdiv64(B, 32), (unsigned)ndir), block((unsigned)g.nw * 64);
+  dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
 #define TAD_FWD(C, BFV)                                                                  \
   (g.jpw == 1 ? launch_fwd<C, BFV, 1>(a, grid, block, lds, s)                             \
@@ -478,6 +537,7 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int64_t B, int64_t T, int64_t H, 
   }
   const int ks = ks_of(bf);
   a.B = (int)B; a.T = (int)T; a.H = (int)H; a.NJ = g.NJ; a.width = g.width;
+  a.rpw = rows_per_wg(B, ndir);
   a.nk_total = g.nkb; a.nk_gate = g.width / ks;
   const int pad = bf ? 8 : 4;
   const size_t esz = bf ? 2 : 4;
@@ -486,7 +546,7 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int64_t B, int64_t T, int64_t H, 
   a.lds_ld = (phased ? g.width : G * g.width) + pad;
   lds = (size_t)32 * a.lds_ld * esz;
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_bwd: H=%ld needs %zu bytes of LDS (limit %zu)", (long)H, lds, LDS_LIMIT);
-  dim3 grid((unsigned)cdiv64(B, 32), (unsigned)ndir), block((unsigned)g.nw * 64);
+  dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
 #define TAD_BWD2(C, BFV, J) (phased ? launch_bwd<C, BFV, J, true>(a, grid, block, lds, s) : launch_bwd<C, BFV, J, false>(a, grid, block, lds, s))
 #define TAD_BWD(C, BFV) (g.jpw == 1 ? TAD_BWD2(C, BFV, 1) : (g.jpw == 2 ? TAD_BWD2(C, BFV, 2) : TAD_BWD2(C, BFV, 4)))

@@ -45,9 +45,47 @@ def _ptr(t):
     return t.data_ptr()
 
 
+class LaunchTrace:
+    """Optional per-call device timing: while installed (``with LaunchTrace() as tr``) every
+    C-ABI call is bracketed by two events on the current stream.  ``summary()`` synchronises
+    once and returns {(entry point, integer args): [calls, total_ms]}."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _TRACE
+        self._prev, _TRACE = _TRACE, self
+        return self
+
+    def __exit__(self, *exc):
+        global _TRACE
+        _TRACE = self._prev
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, e0, e1 in self.records:
+            ent = out.setdefault(key, [0, 0.0])
+            ent[0] += 1
+            ent[1] += e0.elapsed_time(e1)
+        return out
+
+
+_TRACE = None
+
+
 def _call(name, *args):
     lib = _lib.load()
-    rc = getattr(lib, name)(*args)
+    if _TRACE is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        _TRACE.records.append(((name,) + tuple(a for a in args[:6] if isinstance(a, int) and abs(a) < (1 << 40)), e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise _lib.TadError(f"{name}: {lib.tad_last_error().decode()}")
 
