@@ -58,10 +58,12 @@ int tad_linear_bwd_data(int prec, int64_t M, int64_t N, int64_t K, const float* 
  * accumulates (float atomics across M-slabs).  If T > 0 the rows of X are read
  * time-shifted inside windows of T rows: X'[b*T+t] = X[b*T+t+tshift] when
  * 0 <= t+tshift < T, else 0 -- the h_{t-1} operand of the recurrent weight gradient
- * in BPTT (autograd of DIFF.py:182, 189; VAE.py:119-120). */
+ * in BPTT (autograd of DIFF.py:182, 189; VAE.py:119-120).  If db != NULL the bias
+ * gradient db[n] += sum_m dY[m,n] is accumulated in the same pass (and into db2 as
+ * well when that is given: the b_ih / b_hh pair of an LSTM receives the same sum). */
 int tad_linear_bwd_weight(int prec, int64_t M, int64_t N, int64_t K, const float* dY, int64_t ldy,
-                          const float* X, int64_t ldx, float* dW, int64_t ldw, int64_t T, int64_t tshift,
-                          tad_stream_t stream);
+                          const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, float* db2,
+                          int64_t T, int64_t tshift, tad_stream_t stream);
 
 /* Column sums: out_sum[n] += sum_m dY[m,n]; if out_wsum != NULL also
  * out_wsum[n] += sum_m dY[m,n] * row_scale[m*row_scale_stride] * scale_mul.

@@ -103,6 +103,14 @@ def test_linear_bwd_weight(ops, dev, prec, M, N, K):
     dW = torch.full((N, K), 0.25, device=dev)
     ops.linear_bwd_weight(prec, D(dY, dev), D(X, dev), dW)
     assert fu.rel_err(dW.cpu().numpy(), ref + 0.25) < F32_TOL
+    # bias gradients in the same pass: unrounded fp32 column sums of dY in both precisions
+    dW.fill_(0.25)
+    db, db2 = torch.full((N,), 0.5, device=dev), torch.full((N,), -1.0, device=dev)
+    ops.linear_bwd_weight(prec, D(dY, dev), D(X, dev), dW, db=db, db2=db2)
+    cs = dY.astype(np.float64).sum(0)
+    assert fu.rel_err(dW.cpu().numpy(), ref + 0.25) < F32_TOL
+    assert fu.rel_err(db.cpu().numpy(), cs + 0.5) < F32_TOL
+    assert fu.rel_err(db2.cpu().numpy(), cs - 1.0) < F32_TOL
 
 
 @pytest.mark.parametrize("prec", [0, 1])

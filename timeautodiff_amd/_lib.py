@@ -35,7 +35,7 @@ PROTOTYPES = {
     "tad_last_error": (C.c_char_p, []),
     "tad_linear_fwd": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i, _p]),
     "tad_linear_bwd_data": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
-    "tad_linear_bwd_weight": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
+    "tad_linear_bwd_weight": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _p]),
     "tad_colsum": (_i, [_i64, _i64, _p, _i64, _p, _i64, _f, _p, _p, _p, _p]),
     "tad_rnn_fwd": (_i, [_i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p]),
     "tad_rnn_bwd": (_i, [_i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnBwdDir), _p]),

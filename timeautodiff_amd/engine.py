@@ -233,25 +233,25 @@ class RnnStack:
             ops.rnn_bwd(self.cell, prec, B, T, H, dirs)
             shared = self.mode == "bidir" or layer == 0
             in_l = self.in_l(layer)
-            # input-side weights and biases
+            # input-side weights; the bias gradients ride along as column sums of the same dgates:
+            # LSTM b_ih and b_hh both receive sum(dg); GRU b_hh receives sum(dgh) with the W_hh pass
+            gb_ih = fp.ggroup(self.name("bias_ih", layer, 0), 1, nd * GH).view(-1)
+            gb_hh = fp.ggroup(self.name("bias_hh", layer, 0), 1, nd * GH).view(-1)
+            lstm = self.cell == CELL_LSTM
             if shared:
-                ops.linear_bwd_weight(prec, dg, inp, fp.ggroup(self.name("weight_ih", layer, 0), nd * GH, in_l))
+                ops.linear_bwd_weight(prec, dg, inp, fp.ggroup(self.name("weight_ih", layer, 0), nd * GH, in_l),
+                                      db=gb_ih, db2=gb_hh if lstm else None)
             else:
                 for d in range(nd):
-                    ops.linear_bwd_weight(prec, dg[:, d * GH:(d + 1) * GH], inp[:, d * H:(d + 1) * H],
-                                          fp.g(self.name("weight_ih", layer, d)))
-            gb_ih = fp.ggroup(self.name("bias_ih", layer, 0), 1, nd * GH)
-            gb_hh = fp.ggroup(self.name("bias_hh", layer, 0), 1, nd * GH)
-            if self.cell == CELL_LSTM:
-                ops.colsum(dg, out_sum=gb_ih, out_sum2=gb_hh)
-            else:
-                ops.colsum(dg, out_sum=gb_ih)
-                ops.colsum(dgh, out_sum=gb_hh)
+                    sl = slice(d * GH, (d + 1) * GH)
+                    ops.linear_bwd_weight(prec, dg[:, sl], inp[:, d * H:(d + 1) * H], fp.g(self.name("weight_ih", layer, d)),
+                                          db=gb_ih[sl], db2=gb_hh[sl] if lstm else None)
             # recurrent weights: dW_hh += dgates^T h_{t-1}
-            src = dgh if self.cell == CELL_GRU else dg
+            src = dg if lstm else dgh
             for d in range(nd):
-                ops.linear_bwd_weight(prec, src[:, d * GH:(d + 1) * GH], out[:, d * H:(d + 1) * H],
-                                      fp.g(self.name("weight_hh", layer, d)), T=T, tshift=(1 if self.rev[d] else -1))
+                sl = slice(d * GH, (d + 1) * GH)
+                ops.linear_bwd_weight(prec, src[:, sl], out[:, d * H:(d + 1) * H], fp.g(self.name("weight_hh", layer, d)),
+                                      db=None if lstm else gb_hh[sl], T=T, tshift=(1 if self.rev[d] else -1))
             # gradient wrt the layer input
             if layer > 0 or need_dx:
                 dx = ws.get(f"{tag}.dx{layer}", (BT, in_l if shared else nd * H))
@@ -323,12 +323,10 @@ class EmbBlock:
         a2 = ws.get(f"{tag}.a2", (rows, E))
         da2 = ws.get(f"{tag}.da2", (rows, E))
         ops.linear_bwd_data(prec, dout, fp.p(pre + "mlp_output.2.weight"), da2, relu_of=a2)
-        ops.linear_bwd_weight(prec, dout, a2, fp.g(pre + "mlp_output.2.weight"))
-        ops.colsum(dout, out_sum=fp.g(pre + "mlp_output.2.bias"))
+        ops.linear_bwd_weight(prec, dout, a2, fp.g(pre + "mlp_output.2.weight"), db=fp.g(pre + "mlp_output.2.bias"))
         decat = ws.get(f"{tag}.decat", (rows, self.cat_dim))
         ops.linear_bwd_data(prec, da2, fp.p(pre + "mlp_output.0.weight"), decat)
-        ops.linear_bwd_weight(prec, da2, ecat, fp.g(pre + "mlp_output.0.weight"))
-        ops.colsum(da2, out_sum=fp.g(pre + "mlp_output.0.bias"))
+        ops.linear_bwd_weight(prec, da2, ecat, fp.g(pre + "mlp_output.0.weight"), db=fp.g(pre + "mlp_output.0.bias"))
         if nd:
             gt = fp.ggroup(f"{pre}embeddings_list.0.weight", sum(self.cards), E)
             ops.embed_bwd(x[:, :nd], decat[:, :nd * E], gt, self.tab_off, self.cards, E)
@@ -339,20 +337,17 @@ class EmbBlock:
             dy1 = decat[:, nd * E:]
             da1 = ws.get(f"{tag}.da1", (rows, 16 * nn))
             ops.linear_bwd_data(prec, dy1, fp.p(pre + "mlp_nums.2.weight"), da1)
-            ops.linear_bwd_weight(prec, dy1, a1, fp.g(pre + "mlp_nums.2.weight"))
-            ops.colsum(dy1, out_sum=fp.g(pre + "mlp_nums.2.bias"))
+            ops.linear_bwd_weight(prec, dy1, a1, fp.g(pre + "mlp_nums.2.weight"), db=fp.g(pre + "mlp_nums.2.bias"))
             dz1 = ws.get(f"{tag}.dz1", (rows, 16 * nn))
             ops.silu_bwd(z1, da1, dz1)
-            ops.linear_bwd_weight(prec, dz1, feats, fp.g(pre + "mlp_nums.0.weight"))
-            ops.colsum(dz1, out_sum=fp.g(pre + "mlp_nums.0.bias"))
+            ops.linear_bwd_weight(prec, dz1, feats, fp.g(pre + "mlp_nums.0.weight"), db=fp.g(pre + "mlp_nums.0.bias"))
 
 
 def _lin_bwd(prec, dy, x, w, gw, gb, dx=None, relu_of=None, accumulate=False):
     """Backward of y = x W^T + b: weight/bias grads always, input grad if dx is given."""
     if dx is not None:
         ops.linear_bwd_data(prec, dy, w, dx, relu_of=relu_of, accumulate=accumulate)
-    ops.linear_bwd_weight(prec, dy, x, gw)
-    ops.colsum(dy, out_sum=gb)
+    ops.linear_bwd_weight(prec, dy, x, gw, db=gb)
 
 
 # ---------------------------------------------------------------------------

@@ -119,12 +119,15 @@ def linear_bwd_data(prec, dy, w, dx, relu_of=None, accumulate=False):
     _call("tad_linear_bwd_data", prec, M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream())
 
 
-def linear_bwd_weight(prec, dy, x, dw, T=0, tshift=0):
+def linear_bwd_weight(prec, dy, x, dw, db=None, db2=None, T=0, tshift=0):
+    """dw += dy^T x (time-shifted x rows if T > 0); db (and db2) += column sums of dy in the same pass."""
     dyp, M, N, ldy = as2d(dy)
     xp, Mx, K, ldx = as2d(x)
     dwp, Nw, Kw, ldw = as2d(dw)
     assert M == Mx and N == Nw and K == Kw, (dy.shape, x.shape, dw.shape)
-    _call("tad_linear_bwd_weight", prec, M, N, K, dyp, ldy, xp, ldx, dwp, ldw, T, tshift, _stream())
+    for b in (db, db2):
+        assert b is None or (b.is_contiguous() and b.numel() == N), (N, None if b is None else b.shape)
+    _call("tad_linear_bwd_weight", prec, M, N, K, dyp, ldy, xp, ldx, dwp, ldw, _ptr(db), _ptr(db2), T, tshift, _stream())
 
 
 def colsum(dy, out_sum=None, out_sum2=None, row_scale=None, row_scale_stride=1, scale_mul=1.0, out_wsum=None):
