@@ -55,7 +55,8 @@ def synth(n, seed, dev):
 
 
 def fwd_macs_per_sample():
-    """Algorithmic MACs of one denoiser forward per window (SURVEY section 8d formula)."""
+    """Algorithmic MACs of one denoiser forward per window (every matrix product of BiRNN_score.forward,
+    DIFF.py:197-229, at the bench shape)."""
     nd, nn = 1, 27
     emb = 2 * (16 * nn) ** 2 + (E * nd + 16 * nn) * E + E * E
     per_t = (K * H + 2 * (H // 2) + (8 * H + H * H) + emb + 6 * H * (E + H) + 18 * H * H + 2 * H * H + 4 * H * H
@@ -168,28 +169,42 @@ def main():
     ms_step = 1e3 * dt / a.steps
     train_rate = B_LOCAL * world * a.steps / dt
 
-    # ---- per-kernel device timing of the same step (separate, untimed pass)
+    # ---- per-kernel device timing of the same step (separate pass after the timed region; HIP events
+    # on the launch stream around every C-ABI call, aggregated by the device kernel the call launched)
+    NTR = 3
     with ops.LaunchTrace() as tr:
-        for _ in range(3):
+        for _ in range(NTR):
             trainer.step()
-    summ = tr.summary()
-    fam = {}
-    for key, (cnt, ms) in summ.items():
-        kind, fl, by = kernel_cost(key)
-        ent = fam.setdefault(key[0], dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-        ent["calls"] += cnt
-        ent["ms"] += ms
-        ent["flops"] += fl * cnt
-        ent["bytes"] += by * cnt
-    dom_key = max(summ, key=lambda k: summ[k][1])
-    cnt, ms = summ[dom_key]
-    kind, fl, by = kernel_cost(dom_key)
-    avg_s = ms / cnt * 1e-3
-    roof = dict(bound="mfma", kernel=f"{dom_key[0]}{list(dom_key[1:])}", achieved=round(fl / avg_s / 1e12, 2), peak=PEAK_BF16 / 1e12,
-                unit="TFLOP/s", frac=round(fl / avg_s / PEAK_BF16, 4), traffic=None, avg_launch_ms=round(ms / cnt, 4),
-                launches_per_step=cnt // 3, hbm_GBps_algorithmic=round(by / avg_s / 1e9, 1))
-    kernels = {k: dict(calls_per_step=v["calls"] // 3, ms_per_step=round(v["ms"] / 3, 3),
-                       tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+    by_kernel = tr.summary_by_kernel()
+    kstat = {}
+    for kern, calls in by_kernel.items():
+        ent = kstat.setdefault(kern, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+        for key, (cnt, ms) in calls.items():
+            _, fl, by = kernel_cost(key)
+            ent["calls"] += cnt
+            ent["ms"] += ms
+            ent["flops"] += fl * cnt
+            ent["bytes"] += by * cnt
+    dom = max(kstat, key=lambda k: kstat[k]["ms"])
+    d = kstat[dom]
+    avg_s = d["ms"] / d["calls"] * 1e-3
+    fl_l, by_l = d["flops"] / d["calls"], d["bytes"] / d["calls"]          # algorithmic work of an average launch
+    # the roofline that binds: below the ridge (peak FLOP/s / peak B/s) a kernel is HBM-bound
+    hbm_bound = by_l > 0 and fl_l / by_l < PEAK_BF16 / PEAK_HBM
+    if hbm_bound:
+        roof = dict(bound="hbm", achieved=round(by_l / avg_s / 1e9, 1), peak=PEAK_HBM / 1e9, unit="GB/s",
+                    frac=round(by_l / avg_s / PEAK_HBM, 4), traffic=None)
+    else:
+        roof = dict(bound="mfma", achieved=round(fl_l / avg_s / 1e12, 2), peak=PEAK_BF16 / 1e12, unit="TFLOP/s",
+                    frac=round(fl_l / avg_s / PEAK_BF16, 4), traffic=None)
+    roof.update(kernel=dom, avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=d["calls"] // NTR,
+                algorithmic_bytes_per_launch=round(by_l), algorithmic_flops_per_launch=round(fl_l),
+                tflops=round(fl_l / avg_s / 1e12, 2), share_of_step=round(d["ms"] / NTR / ms_step, 3))
+    kernels = {k: dict(launches_per_step=v["calls"] // NTR, ms_per_step=round(v["ms"] / NTR, 3),
+                       avg_us=round(v["ms"] / v["calls"] * 1e3, 1),
+                       tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                       hbm_GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
+               for k, v in sorted(kstat.items(), key=lambda kv: -kv[1]["ms"])[:12]}
 
     # ---- sampler: 1k sequences per GPU, 100 reverse steps
     sampler = None

@@ -35,6 +35,10 @@ enum { TAD_CELL_LSTM = 0, TAD_CELL_GRU = 1 };
 
 int tad_abi_version(void);
 const char* tad_last_error(void);
+/* Name (template arguments included, as a profiler prints it) of the device kernel that the calling
+ * thread's most recent entry point launched, or "" if it launched none it names; reading clears it.
+ * No counterpart in the reference: it lets a benchmark attribute device time per kernel. */
+const char* tad_last_kernel(void);
 
 /* ------------------------------------------------------------------ linear family
  * nn.Linear forward: Y[M,N] = act(X[M,K] W[N,K]^T + bias + bias2 + residual).

@@ -33,6 +33,7 @@ class RnnBwdDir(C.Structure):
 PROTOTYPES = {
     "tad_abi_version": (_i, []),
     "tad_last_error": (C.c_char_p, []),
+    "tad_last_kernel": (C.c_char_p, []),
     "tad_linear_fwd": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i, _p]),
     "tad_linear_bwd_data": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "tad_linear_bwd_weight": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _p]),

@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 // error plumbing (host)
 void tad_set_error(const char* fmt, ...);
+void tad_note_kernel(const char* fmt, ...);   // records the launched kernel's name for tad_last_kernel()
 #define TAD_CHECK(cond, ...)            \
   do {                                  \
     if (!(cond)) {                      \

@@ -324,7 +324,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], const Gemm
 }
 
 template <bool BF16, bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : 3) : 1)) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 ? 3 : 2)) : 1)) void gemm_kernel(GemmParams p) {
   constexpr int NT = 64 * WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int ROWB = BF16 ? 64 : 128;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
@@ -473,21 +473,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : 3) : 1
   STAMP(ts2);
 
   if constexpr (!A_KC) {
-    if (want_rowsum) {
+    if (want_rowsum) {     // uniform over the workgroup
+      // several threads hold partial sums of one row: combine them through LDS (free after the last
+      // barrier of the k-loop), then one atomic per row -- every split of the reduction adds into the
+      // same few hundred addresses, so the atomics are kept as few as possible
+      constexpr int PARTS = VEC ? NT / (BM / 4) : NT / BM;
+      float* red = reinterpret_cast<float*>(smem);           // [PARTS][BM]
+      static_assert(PARTS * BM * 4 <= 2 * (A_BYTES + B_BYTES), "reduction scratch fits the tile buffers");
       if constexpr (VEC) {
-        const int64_t i = i0 + 4 * (tid % (BM / 4));
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (i + q < p.M) {
-            atomicAdd(&p.rowsum[i + q], rsum[q]);
-            if (p.rowsum2) atomicAdd(&p.rowsum2[i + q], rsum[q]);
-          }
+        const int rq = tid % (BM / 4), kg = tid / (BM / 4);
+        *reinterpret_cast<float4*>(red + kg * BM + 4 * rq) = make_float4(rsum[0], rsum[1], rsum[2], rsum[3]);
       } else {
-        const int64_t i = i0 + tid % BM;
-        if (i < p.M) {
-          atomicAdd(&p.rowsum[i], rsum[0]);
-          if (p.rowsum2) atomicAdd(&p.rowsum2[i], rsum[0]);
-        }
+        red[(tid / BM) * BM + tid % BM] = rsum[0];
+      }
+      __syncthreads();
+      if (tid < BM && i0 + tid < p.M) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) sum += red[q * BM + tid];
+        atomicAdd(&p.rowsum[i0 + tid], sum);
+        if (p.rowsum2) atomicAdd(&p.rowsum2[i0 + tid], sum);
       }
     }
   }
@@ -532,8 +537,11 @@ void launch_cfg(GemmParams& p, int splits, hipStream_t s) {
   p.tiles_n = cdiv64(p.N, BN);
   p.ntiles = cdiv64(p.M, BM) * p.tiles_n;
   dim3 grid((unsigned)p.ntiles, 1, (unsigned)splits);
-  if (vec_ok(p, A_KC, B_KC)) hipLaunchKernelGGL((gemm_kernel<BF16, A_KC, B_KC, true, WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, s, p);
+  const bool vec = vec_ok(p, A_KC, B_KC);
+  if (vec) hipLaunchKernelGGL((gemm_kernel<BF16, A_KC, B_KC, true, WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, s, p);
   else hipLaunchKernelGGL((gemm_kernel<BF16, A_KC, B_KC, false, WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, s, p);
+  auto tf = [](bool b) { return b ? "true" : "false"; };
+  tad_note_kernel("gemm_kernel<%s, %s, %s, %s, %d, %d, %d, %d>", tf(BF16), tf(A_KC), tf(B_KC), tf(vec), WM, WN, TM, TN);
 }
 
 enum Cfg { CFG_W, CFG_S, CFG_F, CFG_T, CFG_H };

@@ -445,6 +445,7 @@ int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream
   if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
+  tad_note_kernel("rnn_fwd_kernel<%d, %s, %d>", CELL, BF16 ? "true" : "false", JPW);
   return TAD_OK;
 }
 
@@ -455,6 +456,7 @@ int launch_bwd(const RnnBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream
   if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
+  tad_note_kernel("rnn_bwd_kernel<%d, %s, %d, %s>", CELL, BF16 ? "true" : "false", JPW, PHASED ? "true" : "false");
   return TAD_OK;
 }
 

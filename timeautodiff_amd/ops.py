@@ -65,8 +65,18 @@ class LaunchTrace:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for key, e0, e1 in self.records:
+        for key, _, e0, e1 in self.records:
             ent = out.setdefault(key, [0, 0.0])
+            ent[0] += 1
+            ent[1] += e0.elapsed_time(e1)
+        return out
+
+    def summary_by_kernel(self):
+        """{device kernel name (entry point name if the call names no kernel): {key: [calls, total_ms]}}."""
+        torch.cuda.synchronize()
+        out = {}
+        for key, kern, e0, e1 in self.records:
+            ent = out.setdefault(kern or key[0], {}).setdefault(key, [0, 0.0])
             ent[0] += 1
             ent[1] += e0.elapsed_time(e1)
         return out
@@ -83,7 +93,8 @@ def _call(name, *args):
         e0.record()
         rc = getattr(lib, name)(*args)
         e1.record()
-        _TRACE.records.append(((name,) + tuple(a for a in args[:6] if isinstance(a, int) and abs(a) < (1 << 40)), e0, e1))
+        key = (name,) + tuple(a for a in args[:6] if isinstance(a, int) and abs(a) < (1 << 40))
+        _TRACE.records.append((key, lib.tad_last_kernel().decode(), e0, e1))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:
