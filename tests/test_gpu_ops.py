@@ -199,7 +199,7 @@ def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng):
                 dgh=dgh.cpu().numpy() if dgh is not None else None, oracle=oracle, x=x, dout=dout, kind=kind, G=G, S=S)
 
 
-RNN_CASES = [(5, 6, 24), (37, 5, 40), (70, 4, 200), (33, 3, 272)]
+RNN_CASES = [(5, 6, 24), (37, 5, 40), (70, 4, 200), (33, 3, 272), (9, 4, 30)]
 
 
 @pytest.mark.parametrize("prec", [0, 1])

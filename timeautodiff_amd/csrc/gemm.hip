@@ -53,6 +53,7 @@ struct GemmParams {
   const float* residual; int64_t ld_res;
   float* rowsum; float* rowsum2;   // += sum_k A(i,k) (bias gradients; added by the first column tile)
   int act, atomic;
+  int wide_epi;              // 16-byte epilogue possible (alignment of C, bias, residual, relu operand)
   int64_t k_per_split;
   int shiftT, shift;         // time-shifted rows of the B operand along k (see header)
   int64_t tiles_n, ntiles;
@@ -323,6 +324,82 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], const Gemm
   }
 }
 
+// Same epilogue with 16-byte accesses: the wave passes its accumulators through a private 32 x 64
+// fp32 staging block in LDS (the tile buffers are free once the k-loop is done) and reads them back
+// row-major, 4 consecutive columns per lane, so C, the residual and the relu operand move as 16
+// bytes per lane: a quarter of the vector-memory instructions of the dword form.  Needs N, ldc,
+// ld_res, ld_relu multiples of 4 and 16-byte aligned bases.  MODE 0 / 1 only (no wide atomics).
+template <int MODE, int TM, int TN>
+__device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[TM][TN], const GemmParams& p, int64_t ib, int64_t jb,
+                                              int lane, float* stage) {
+  static_assert(TN % 2 == 0 && MODE != 2, "column pairs");
+  const int lr = lane & 31;
+  const int rrow = lane >> 4, c4 = lane & 15;          // read-back: row rrow + 4*pass, columns 4*c4 .. 4*c4+3 of a 64-wide pair
+  const int64_t mrem64 = p.M - ib, nrem64 = p.N - jb;
+  const int mrem = (int)(mrem64 < 32 * TM ? mrem64 : 32 * TM), nrem = (int)(nrem64 < 32 * TN ? nrem64 : 32 * TN);
+  float* cbase = p.C + ib * p.ldc + jb;
+  const uint32_t ldc = (uint32_t)p.ldc;
+  const bool has_res = p.residual != nullptr, has_relu = p.relu_of != nullptr;
+  const float* rbase = has_res ? p.residual + ib * p.ld_res + jb : cbase;
+  const float* ubase = has_relu ? p.relu_of + ib * p.ld_relu + jb : cbase;
+  const uint32_t ldr = has_res ? (uint32_t)p.ld_res : ldc, ldu = has_relu ? (uint32_t)p.ld_relu : ldc;
+  const uint32_t voff = (uint32_t)rrow * ldc + 4u * c4, voff_r = (uint32_t)rrow * ldr + 4u * c4, voff_u = (uint32_t)rrow * ldu + 4u * c4;
+#pragma unroll
+  for (int jp = 0; jp < TN / 2; ++jp) {
+    const int col = 64 * jp + 4 * c4;
+    const bool cok = col < nrem;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      const int cc = cok ? col : 0;
+      if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + jb + cc); bsum.x += b.x; bsum.y += b.y; bsum.z += b.z; bsum.w += b.w; }
+      if (p.bias2) { const float4 b = *reinterpret_cast<const float4*>(p.bias2 + jb + cc); bsum.x += b.x; bsum.y += b.y; bsum.z += b.z; bsum.w += b.w; }
+    }
+#pragma unroll
+    for (int it = 0; it < TM; ++it) {
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[acc_row32(r, lane) * 64 + 32 * j2 + lr] = acc[it][2 * jp + j2][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float4 res[8], rel[8];
+      if constexpr (MODE == 1) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const int rowl = 32 * it + 4 * ps;
+          const bool ok = cok && rowl + rrow < mrem;
+          const uint32_t urow = rowl < mrem ? (uint32_t)rowl : 0u, ucol = 64 * jp < nrem ? 64u * jp : 0u;
+          res[ps] = *reinterpret_cast<const float4*>((rbase + (urow * ldr + ucol)) + (ok ? voff_r : 0u));
+          rel[ps] = *reinterpret_cast<const float4*>((ubase + (urow * ldu + ucol)) + (ok ? voff_u : 0u));
+        }
+      }
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int rowl = 32 * it + 4 * ps;
+        const bool ok = cok && rowl + rrow < mrem;
+        float4 v = *reinterpret_cast<const float4*>(stage + (4 * ps + rrow) * 64 + 4 * c4);
+        v.x += bsum.x; v.y += bsum.y; v.z += bsum.z; v.w += bsum.w;
+        if constexpr (MODE == 1) {
+          if (has_res) { v.x += res[ps].x; v.y += res[ps].y; v.z += res[ps].z; v.w += res[ps].w; }
+        }
+        if (p.act == TAD_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if constexpr (MODE == 1) {
+          if (has_relu) {
+            if (!(rel[ps].x > 0.f)) v.x = 0.f;
+            if (!(rel[ps].y > 0.f)) v.y = 0.f;
+            if (!(rel[ps].z > 0.f)) v.z = 0.f;
+            if (!(rel[ps].w > 0.f)) v.w = 0.f;
+          }
+        }
+        if (ok) *reinterpret_cast<float4*>((cbase + ((uint32_t)rowl * ldc + 64u * jp)) + voff) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 template <bool BF16, bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 ? 3 : 2)) : 1)) void gemm_kernel(GemmParams p) {
   constexpr int NT = 64 * WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
@@ -400,9 +477,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 
     }
   };
 
+  // Pipeline: registers hold the tile of step t+1 while step t is multiplied.  Each step first moves
+  // those registers into the idle LDS buffer, then issues the loads of step t+2 into the same
+  // registers -- they have a whole step to arrive -- then runs the MFMAs of step t.  Loads are
+  // unconditional: beyond the range they re-read its first tile, which nobody looks at.
   STAMP(ts0);
   gload(kbeg);
   lstore(0, true);
+  gload(nt > 1 ? kbeg + BK : kbeg);
   __syncthreads();
   STAMP(ts1);
 #ifdef EXP_STAMPS
@@ -415,12 +497,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 
   for (int kk = 0; kk < (BF16 ? 2 : 4); ++kk) foff[kk] = lds_off<BF16>(lr, (BF16 ? 16 : 8) * kk + (BF16 ? 8 : 4) * half);
 
   for (int t = 0; t < nt; ++t) {
-    // The loads of the next k-step are in flight under the MFMAs below.  They are unconditional: the
-    // last step re-reads the first tile of the range into the idle buffer, where nobody looks at it.
-    const bool more = t + 1 < nt;
-#ifndef EXP_NOGLOAD
-    gload(more ? kbeg + (int64_t)(t + 1) * BK : kbeg);
-#endif
+    lstore((t + 1) & 1, t + 1 < nt);    // the other buffer: last read one barrier ago
+    STAMP(tC);
+    gload(t + 2 < nt ? kbeg + (int64_t)(t + 2) * BK : kbeg);
     STAMP(tA);
     const unsigned char* As = smem + (size_t)(t & 1) * (A_BYTES + B_BYTES) + (32 * TM * wm) * ROWB;
     const unsigned char* Bs = smem + (size_t)(t & 1) * (A_BYTES + B_BYTES) + A_BYTES + (32 * TN * wn) * ROWB;
@@ -460,14 +539,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 
       }
     }
     STAMP(tB);
-#ifndef EXP_NOLSTORE
-    lstore((t + 1) & 1, more);    // the other buffer: last read one barrier ago
-#endif
-    STAMP(tC);
     __syncthreads();
     STAMP(tD);
 #ifdef EXP_STAMPS
-    sA += tA - tprev; sB += tB - tA; sC += tC - tB; sD += tD - tC; tprev = tD;
+    sC += tC - tprev; sA += tA - tC; sB += tB - tA; sD += tD - tB; tprev = tD;
 #endif
   }
   STAMP(ts2);
@@ -494,10 +569,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 
         atomicAdd(&p.rowsum[i0 + tid], sum);
         if (p.rowsum2) atomicAdd(&p.rowsum2[i0 + tid], sum);
       }
+      __syncthreads();
     }
   }
 
-  if (active) {
+  if (active && !p.atomic && p.wide_epi) {
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+    static_assert((NT / 64) * 32 * 64 * 4 <= 2 * (A_BYTES + B_BYTES), "staging blocks fit the tile buffers");
+    if (p.residual || p.relu_of) epilogue_wide<1>(acc, p, ib, jb, lane, stage);
+    else epilogue_wide<0>(acc, p, ib, jb, lane, stage);
+  } else if (active) {
     const bool full = ib + 32 * TM <= p.M && jb + 32 * TN <= p.N;
     if (p.atomic) {
       if (full) epilogue<2, true>(acc, p, ib, jb, lane); else epilogue<2, false>(acc, p, ib, jb, lane);
@@ -537,6 +618,9 @@ void launch_cfg(GemmParams& p, int splits, hipStream_t s) {
   p.tiles_n = cdiv64(p.N, BN);
   p.ntiles = cdiv64(p.M, BM) * p.tiles_n;
   dim3 grid((unsigned)p.ntiles, 1, (unsigned)splits);
+  p.wide_epi = !p.atomic && p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && (!p.bias || aligned16(p.bias)) &&
+               (!p.bias2 || aligned16(p.bias2)) && (!p.residual || (p.ld_res % 4 == 0 && aligned16(p.residual))) &&
+               (!p.relu_of || (p.ld_relu % 4 == 0 && aligned16(p.relu_of)));
   const bool vec = vec_ok(p, A_KC, B_KC);
   if (vec) hipLaunchKernelGGL((gemm_kernel<BF16, A_KC, B_KC, true, WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, s, p);
   else hipLaunchKernelGGL((gemm_kernel<BF16, A_KC, B_KC, false, WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, s, p);

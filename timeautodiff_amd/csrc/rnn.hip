@@ -14,6 +14,14 @@
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = batch row within the tile.
 #include "common.h"
 
+// Diagnostic build only (-DEXP_STAMPS): per-phase cycle counts of wave 0, summed over workgroups and steps.
+#ifdef EXP_STAMPS
+__device__ unsigned long long g_rstamps[8];
+#define RSTAMP(var) __builtin_amdgcn_sched_barrier(0); unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0)
+#else
+#define RSTAMP(var)
+#endif
+
 namespace {
 
 constexpr int MAXDIR = 2;
@@ -194,6 +202,9 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
     if (wave < a.NJ) load_xp(0, 0, nacc, nxn);
   }
 
+#ifdef EXP_STAMPS
+  unsigned long long stamp_prev = 0;
+#endif
   for (int step = 0; step < T; ++step) {
     const int tt = d.reverse ? T - 1 - step : step;
     const unsigned char* cur = smem + (size_t)(step & 1) * buf_bytes;
@@ -206,18 +217,29 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
         const bool uok = u < H;
         f32x16 acc[G];
         float xn[16];
+        RSTAMP(q0);
         if constexpr (PREFETCH) {
 #pragma unroll
           for (int g = 0; g < G; ++g) acc[g] = nacc[g];
 #pragma unroll
           for (int r = 0; r < 16; ++r) xn[r] = nxn[r];
+#ifdef EXP_STAMPS
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the prefetched values have landed
+#endif
         } else {
           load_xp(step, jj, acc, xn);
         }
+        RSTAMP(q1);
         mma_stream<BF16, G, PF>(acc, cur, a.lds_ld, wp + (int64_t)j * a.nk * G * 64, a.nk, lane);
+        RSTAMP(q2);
         if constexpr (PREFETCH) {
           if (step + 1 < T) load_xp(step + 1, 0, nacc, nxn);
         }
+        RSTAMP(q3);
+#ifdef EXP_STAMPS
+        if (threadIdx.x == 0) { atomicAdd(&g_rstamps[0], q1 - q0); atomicAdd(&g_rstamps[1], q2 - q1); atomicAdd(&g_rstamps[2], q3 - q2); }
+        stamp_prev = q3;
+#endif
         const int ooff = (4 * half * T + tt) * (int)d.ld_out + u;
         const int soff = (4 * half * T + tt) * (S * H) + u;
 #pragma unroll
@@ -255,7 +277,13 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
         }
       }
     }
+#ifdef EXP_STAMPS
+    { RSTAMP(q4); if (threadIdx.x == 0) atomicAdd(&g_rstamps[3], q4 - stamp_prev); stamp_prev = q4; }
+#endif
     __syncthreads();
+#ifdef EXP_STAMPS
+    { RSTAMP(q5); if (threadIdx.x == 0) { atomicAdd(&g_rstamps[4], q5 - stamp_prev); atomicAdd(&g_rstamps[7], 1ull); } }
+#endif
   }
 }
 
@@ -557,3 +585,12 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int64_t B, int64_t T, int64_t H, 
 #undef TAD_BWD
 #undef TAD_BWD2
 }
+
+#ifdef EXP_STAMPS
+// diagnostic build only: forward kernel, wave 0, summed {seed+wait, mfma stream, prefetch issue, gate math+stores, barrier, -, -, steps}
+extern "C" int tad_dbg_rnn_stamps(unsigned long long* out8, int reset) {
+  if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_rstamps), 64);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_rstamps), z, 64); }
+  return 0;
+}
+#endif
