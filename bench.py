@@ -7,6 +7,8 @@
 Workload (BASELINE.json configs[1]): energy_data-shaped windows (28 features = 1 categorical of
 cardinality 8 + 27 numericals, T = 24, latent K = 6, denoiser H = 200, 2 layers, emb 128),
 bf16 matrix-core operands with fp32 accumulation and fp32 master weights.
+The "sampler" and "vae" objects of the JSON line carry the two companion rates (sampled sequences/s through
+all 100 reverse steps; VAE training samples/s).
 A "step" is one full optimizer step of the denoiser (draws, gather, add_noise, forward, loss,
 backward, gradient all-reduce, Adam) on a per-GPU batch of 4096 windows (weak scaling: the
 global batch is 4096 x N).  The sampler line generates 1024 sequences per GPU through all 100
@@ -125,6 +127,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--no-vae", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,6 +200,17 @@ def main():
     else:
         roof = dict(bound="mfma", achieved=round(fl_l / avg_s / 1e12, 2), peak=PEAK_BF16 / 1e12, unit="TFLOP/s",
                     frac=round(fl_l / avg_s / PEAK_BF16, 4), traffic=None)
+    # HBM traffic per launch of that kernel: PMC counters cannot be collected from inside this process, so the
+    # figure is the one measured by scripts/pmc_traffic.sh on this same step (committed under profiles/)
+    try:
+        import glob
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+        tk = json.load(open(tf))["kernels"].get(dom)
+        if tk:
+            roof["traffic"] = tk["traffic_bytes_per_launch"]
+            roof["traffic_source"] = os.path.relpath(tf, ROOT)
+    except (IndexError, OSError, KeyError, ValueError):
+        pass
     roof.update(kernel=dom, avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=d["calls"] // NTR,
                 algorithmic_bytes_per_launch=round(by_l), algorithmic_flops_per_launch=round(fl_l),
                 tflops=round(fl_l / avg_s / 1e12, 2), share_of_step=round(d["ms"] / NTR / ms_step, 3))
@@ -228,6 +242,36 @@ def main():
         sampler = dict(metric="sampled_seqs_per_sec", value=round(Bs * reps / ds, 1), unit="seqs/s", batch_per_gpu=B_SAMPLE,
                        reverse_steps=STEPS_DIFF, ms_per_call=round(1e3 * ds / reps, 2))
 
+    # ---- VAE: full optimizer steps of the mixed-type autoencoder on the same windows (third line)
+    vae = None
+    if not a.no_vae:
+        from timeautodiff_amd.VAE import DeapStack, VAETrainer
+        NV = 4 * B_LOCAL
+        ones = torch.ones(NV, T, F, device=dev)
+        dd = dict(response_train=cond[:NV], target_mask_train=ones, cond_train=None,
+                  response_val=cond[NV:NV + 256], target_mask_val=ones[:256], cond_val=None)
+        torch.manual_seed(4321)
+        ae = DeapStack(1, 0, 1, 27, [8], F, H, LAYERS, E, 8, K)
+        vt = VAETrainer(ae, dd, batch_size=B_LOCAL * world, lr=2e-4, weight_decay=1e-6, dtype=a.dtype, process_group=pg, dev=dev)
+        import random
+        random.seed(99)                       # same batch indices on every rank
+        for _ in range(2):
+            vt.train_step(0.1)
+        barrier()
+        t2 = time.perf_counter()
+        vsteps = max(3, a.steps // 2)
+        for _ in range(vsteps):
+            vt.train_step(0.1)
+        barrier()
+        dv = time.perf_counter() - t2
+        if world > 1:
+            tt = torch.tensor([dv], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dv = float(tt.item())
+        vae = dict(metric="vae_train_samples_per_sec", value=round(B_LOCAL * world * vsteps / dv, 1), unit="samples/s",
+                   steps=vsteps, ms_per_step=round(1e3 * dv / vsteps, 3), per_gpu_batch=B_LOCAL,
+                   model="DeapStack F=28 hidden 200, 2-layer GRU x2, emb 128, latent 6")
+
     if rank == 0:
         macs = fwd_macs_per_sample()
         out = dict(metric="denoiser_train_samples_per_sec", value=round(train_rate, 1), unit="samples/s", n_gpus=world,
@@ -237,7 +281,7 @@ def main():
                                         "BiRNN_score H=200 2 layers emb 128, full optimizer step, per-GPU batch 4096",
                                global_batch=B_LOCAL * world, per_gpu_batch=B_LOCAL, T=T, H=H, parallelism=f"dp{world}"),
                    model_flops_frac_of_bf16_peak=round(3 * 2 * macs * train_rate / (PEAK_BF16 * world), 4),
-                   roofline=roof, kernels=kernels, sampler=sampler)
+                   roofline=roof, kernels=kernels, sampler=sampler, vae=vae)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
