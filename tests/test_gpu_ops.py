@@ -480,3 +480,60 @@ def test_bad_arguments_fail_loudly(ops, dev):
         ops.rnn_fwd(0, 0, 4, 1, 2000, [dict(xproj=x, w_packed=x, out=x, stash=None, reverse=False)])   # H too large
     with pytest.raises(TadError):
         ops.linear_fwd(0, torch.zeros(4, 4), x, None, x)                                                  # host tensor
+
+
+# ------------------------------------------------------------------ edge cases
+def test_empty_batch_is_a_no_op(ops, dev):
+    """M = 0 (an empty shard of a batch) returns without touching the outputs."""
+    w = torch.ones(8, 4, device=dev)
+    y = torch.full((0, 8), 7.0, device=dev)
+    x = torch.zeros(0, 4, device=dev)
+    lib = ops._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tad_linear_fwd(0, 0, 8, 4, x.data_ptr() or 1, 4, w.data_ptr(), 4, None, None, None, 0, y.data_ptr() or 1, 8, 0, st) == 0
+    dw = torch.full((8, 4), 0.5, device=dev)
+    assert lib.tad_linear_bwd_weight(0, 0, 8, 4, y.data_ptr() or 1, 8, x.data_ptr() or 1, 4, dw.data_ptr(), 4, None, None, 0, 0, st) == 0
+    assert lib.tad_linear_bwd_data(0, 0, 8, 4, y.data_ptr() or 1, 8, w.data_ptr(), 4, x.data_ptr() or 1, 4, None, 0, 0, st) == 0
+    torch.cuda.synchronize()
+    assert float(dw.min()) == 0.5 and float(dw.max()) == 0.5
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_linear_misaligned_operands_use_the_scalar_loaders(ops, dev, prec):
+    """Views that start at an odd element and have odd leading dimensions (no 16-byte access possible)
+    give the same result as aligned copies."""
+    rng = np.random.default_rng(77)
+    M, N, K = 150, 36, 52
+    Xb, Wb, Yb = D(rnd(rng, M, K + 3), dev), D(rnd(rng, N, K + 1, scale=0.3), dev), torch.zeros(M, N + 5, device=dev)
+    X, W, Y = Xb[:, 1:K + 1], Wb[:, 1:K + 1], Yb[:, 3:N + 3]
+    Xr, Wr = X.cpu().numpy(), W.cpu().numpy()
+    if prec:
+        Xr, Wr = bf16_round(Xr), bf16_round(Wr)
+    ref = Xr.astype(np.float64) @ Wr.astype(np.float64).T
+    ops.linear_fwd(prec, X, W, None, Y)
+    assert fu.rel_err(Y.cpu().numpy(), ref) < F32_TOL
+    assert float(Yb[:, :3].abs().max()) == 0.0 and float(Yb[:, N + 3:].abs().max()) == 0.0
+    # backward products on the same misaligned views
+    dY = Y.clone()                      # contiguous copy is aligned; use the strided view instead
+    dX = torch.zeros(M, K + 3, device=dev)
+    ops.linear_bwd_data(prec, Y, W, dX[:, 1:K + 1])
+    Yr = bf16_round(Y.cpu().numpy()) if prec else Y.cpu().numpy()
+    assert fu.rel_err(dX[:, 1:K + 1].cpu().numpy(), Yr.astype(np.float64) @ Wr.astype(np.float64)) < F32_TOL
+    dW = torch.zeros(N, K + 1, device=dev)
+    db = torch.zeros(N, device=dev)
+    ops.linear_bwd_weight(prec, Y, X, dW[:, 1:K + 1], db=db)
+    assert fu.rel_err(dW[:, 1:K + 1].cpu().numpy(), Yr.astype(np.float64).T @ Xr.astype(np.float64)) < F32_TOL
+    assert fu.rel_err(db.cpu().numpy(), Y.cpu().numpy().astype(np.float64).sum(0)) < F32_TOL
+    del dY
+
+
+@pytest.mark.parametrize("cell", [0, 1])
+def test_rnn_single_sequence_and_maximum_hidden_size(ops, dev, cell):
+    """B = 1 (one window) and H = 1024 (the largest hidden size the sequence kernels accept), fp32."""
+    rng = np.random.default_rng(5 + cell)
+    r = _run_rnn(ops, dev, cell, 0, 1, 3, 24, [False, True], rng)
+    for d in range(2):
+        assert fu.rel_err(r["out"][:, d * 24:(d + 1) * 24], r["oracle"][d]["hs"].reshape(3, 24)) < F32_TOL
+    B, T, H = 3, 2, 1024
+    r = _run_rnn(ops, dev, cell, 1, B, T, H, [False], np.random.default_rng(11))
+    assert fu.rel_err(r["out"], r["oracle"][0]["hs"].reshape(B * T, H)) < BF16_EMU_TOL
