@@ -12,7 +12,13 @@
  *     calling thread's last failure;
  *   - `prec` selects the matrix-core operand type: TAD_F32 (v_mfma_f32_32x32x2_f32,
  *     exact fp32 products) or TAD_BF16 (v_mfma_f32_32x32x16_bf16, operands rounded to
- *     bf16, fp32 accumulation).  Everything outside the matrix products is fp32.
+ *     bf16, fp32 accumulation).  Everything outside the matrix products is fp32;
+ *   - the big per-timestep tensors of the recurrent layers (input-side pre-activations,
+ *     gate stash, pre-activation gradients) are stored in the "gate-interleaved" layout:
+ *     column 4*u + s of a direction's block of 4*H columns holds slot s of hidden unit u
+ *     (LSTM slots i,f,g,o; GRU r,z,n and a fourth slot described per tensor), so that a
+ *     lane of the sequence kernels moves all slots of its unit in one access.  Their
+ *     element type (`store`) is TAD_F32 or TAD_BF16 (bf16 only together with prec = TAD_BF16).
  *
  * Each entry point names the reference code it replaces (paths relative to the
  * TimeAutoDiff checkout).  The reference has no FFI layer of its own: these are the
@@ -64,10 +70,31 @@ int tad_linear_bwd_data(int prec, int64_t M, int64_t N, int64_t K, const float* 
  * 0 <= t+tshift < T, else 0 -- the h_{t-1} operand of the recurrent weight gradient
  * in BPTT (autograd of DIFF.py:182, 189; VAE.py:119-120).  If db != NULL the bias
  * gradient db[n] += sum_m dY[m,n] is accumulated in the same pass (and into db2 as
- * well when that is given: the b_ih / b_hh pair of an LSTM receives the same sum). */
+ * well when that is given: the b_ih / b_hh pair of an LSTM receives the same sum).
+ * gate_map (HOST array {H, G, slot0, slot1, slot2, slot3} or NULL): dY is a
+ * gate-interleaved pre-activation gradient (N a multiple of 4*H; column blk*4H + 4u + s);
+ * its product row lands in row blk*G*H + slot_s*H + u of dW (and db, db2), torch's
+ * gate-major parameter order, or is dropped when slot_s < 0. */
 int tad_linear_bwd_weight(int prec, int64_t M, int64_t N, int64_t K, const float* dY, int64_t ldy,
                           const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, float* db2,
-                          int64_t T, int64_t tshift, tad_stream_t stream);
+                          int64_t T, int64_t tshift, const int32_t* gate_map, tad_stream_t stream);
+
+/* The same three products with bf16-STORED operands (bf16 matrix cores, fp32 accumulation):
+ * the input-side products of nn.LSTM / nn.GRU (DIFF.py:182, 189; VAE.py:119-120) when the
+ * pre-activations, their gradients and the weight images live in HBM as bf16.  bf16
+ * operands need 16-byte aligned rows, leading dimensions and extents that are multiples of 8.
+ *   fwd_b16:        Y = act(X W16^T + bias), X fp32, W16 bf16 [N,K], Y fp32 or bf16 (y_dtype);
+ *   bwd_data_b16:   dX = dY16 W16 (+ dX) with the ReLU mask, dY16 bf16 [M,N], W16 bf16 [N,K], dX fp32;
+ *   bwd_weight_b16: dW += dY16^T X' with db/db2, T/tshift and gate_map as above; the bias
+ *                   sums are taken over the bf16 values of dY16. */
+int tad_linear_fwd_b16(int64_t M, int64_t N, int64_t K, const float* X, int64_t ldx, const void* W16, int64_t ldw,
+                       const float* bias, void* Y, int y_dtype, int64_t ldy, int act, tad_stream_t stream);
+int tad_linear_bwd_data_b16(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const void* W16,
+                            int64_t ldw, float* dX, int64_t ldx, const float* relu_of, int64_t ld_relu,
+                            int accumulate, tad_stream_t stream);
+int tad_linear_bwd_weight_b16(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const float* X,
+                              int64_t ldx, float* dW, int64_t ldw, float* db, float* db2, int64_t T,
+                              int64_t tshift, const int32_t* gate_map, tad_stream_t stream);
 
 /* Column sums: out_sum[n] += sum_m dY[m,n]; if out_wsum != NULL also
  * out_wsum[n] += sum_m dY[m,n] * row_scale[m*row_scale_stride] * scale_mul.
@@ -80,44 +107,52 @@ int tad_colsum(int64_t M, int64_t N, const float* dY, int64_t ldy, const float* 
 /* ------------------------------------------------------------------ recurrent family
  * Per-direction arguments of the persistent LSTM / GRU sequence kernels.  xproj holds
  * the input-side pre-activations x_t W_ih^T (+ b_ih, and + b_hh for LSTM) for all
- * time steps; the kernel adds h_{t-1} W_hh^T, applies the gate nonlinearities and
- * walks T steps with h (and c) resident on chip. */
+ * time steps, gate-interleaved; the kernel adds h_{t-1} W_hh^T, applies the gate
+ * nonlinearities and walks T steps with h (and c) resident on chip.  Typed pointers
+ * (void*) hold `store` elements; they need 16-byte aligned bases and leading
+ * dimensions that are multiples of 4. */
 typedef struct {
-  const float* xproj;   /* [B,T,G*H], row stride ld_xproj (G = 4 LSTM, 3 GRU) */
+  const void* xproj;    /* [B*T, 4H] of this direction (slots i,f,g,o / r,z,n,unused), row stride ld_xproj */
   int64_t ld_xproj;
   const void* w_packed; /* from tad_rnn_pack_weights (forward image) */
-  const float* b_hh;    /* GRU: recurrent bias [3H]; LSTM: NULL */
+  const float* b_hh;    /* GRU: recurrent bias [3H] (r,z,n); LSTM: NULL */
   float* out;           /* h_t -> out[(b*T+t)*ld_out + u], u < H */
   int64_t ld_out;
-  float* stash;         /* training: [B,T,S*H], S = 5 (i,f,g,o,c) LSTM / 4 (r,z,n,W_hn h+b_hn) GRU; NULL = inference */
+  void* gates;          /* training: [B*T, 4H] gate stash (LSTM i,f,g,o; GRU r,z,n,W_hn h+b_hn), row stride ld_gates; NULL = inference */
+  int64_t ld_gates;
+  float* cstate;        /* LSTM training: c_t -> cstate[(b*T+t)*ld_c + u] (fp32); GRU: NULL */
+  int64_t ld_c;
   int32_t reverse;      /* 0: t = 0..T-1, 1: t = T-1..0 */
   int32_t pad_;
 } tad_rnn_dir_t;
 
 /* nn.LSTM / nn.GRU forward over one layer, ndir (1 or 2) independent directions or
  * heads in one launch (DIFF.py:182 -> 220, DIFF.py:189 -> 215, VAE.py:119-120 -> 154-155). */
-int tad_rnn_fwd(int cell, int prec, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
+int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
                 tad_stream_t stream);
 
 typedef struct {
   const float* dout;      /* grad wrt h_t outputs, row stride ld_dout */
   int64_t ld_dout;
-  const float* stash;     /* written by tad_rnn_fwd */
-  const float* out;       /* forward outputs h_t (GRU reads h_{t-1}); row stride ld_out */
+  const void* gates;      /* written by tad_rnn_fwd */
+  int64_t ld_gates;
+  const float* cstate;    /* LSTM: written by tad_rnn_fwd */
+  int64_t ld_c;
+  const float* out;       /* GRU: forward outputs h_t (h_{t-1} is read); row stride ld_out */
   int64_t ld_out;
   const void* w_packed_t; /* from tad_rnn_pack_weights (backward image) */
-  float* dgates;          /* LSTM: [B,T,4H] grads of the pre-activations; GRU: [B,T,3H] input-side (r,z,n) */
-  float* dgates_h;        /* GRU: [B,T,3H] hidden-side (r,z,r*n-part); LSTM: NULL */
-  int64_t ld_dgates;      /* row stride of dgates and dgates_h (>= G*H) */
+  void* dgates;           /* [B*T, 4H] grads of the pre-activations: LSTM i,f,g,o; GRU r, z, n (input side), n (hidden side: r * dn) */
+  int64_t ld_dgates;
   int32_t reverse;
   int32_t pad_;
 } tad_rnn_bwd_dir_t;
 
 /* BPTT through one LSTM / GRU layer (autograd of the calls above): emits the
  * pre-activation gradients; the weight/bias/input gradients follow from them with
- * tad_linear_bwd_weight / tad_colsum / tad_linear_bwd_data. */
-int tad_rnn_bwd(int cell, int prec, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_bwd_dir_t* dirs,
-                tad_stream_t stream);
+ * tad_linear_bwd_weight(_b16) (gate maps {0,1,2,3} LSTM; GRU input side {0,1,2,-1},
+ * hidden side {0,1,-1,2}) and tad_linear_bwd_data(_b16) on the gate-interleaved weights. */
+int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir,
+                const tad_rnn_bwd_dir_t* dirs, tad_stream_t stream);
 
 /* Bytes of ONE packed image of a recurrent weight matrix W_hh[G*H,H]. */
 int64_t tad_rnn_packed_bytes(int prec, int64_t H, int G);
@@ -126,6 +161,14 @@ int64_t tad_rnn_packed_bytes(int prec, int64_t H, int G);
  * Either output may be NULL. */
 int tad_rnn_pack_weights(int prec, int64_t H, int G, const float* w_hh, void* packed_fwd, void* packed_bwd,
                          tad_stream_t stream);
+/* Gate-interleaved image of the input-side parameters of nblk directions / heads:
+ * w_ih [nblk*G*H, in_dim] (torch's gate-major rows, blocks back to back), b_ih and b_hh
+ * [nblk*G*H] -> w_gl [nblk*4H, in_dim] with row blk*4H + 4u + s = row blk*G*H + s*H + u
+ * of w_ih (zero rows for the unused slot of a GRU), as fp32 or bf16 (w_dtype; row stride
+ * ld_gl >= in_dim, columns in_dim..ld_gl-1 zero), and bias_gl [nblk*4H] fp32 = b_ih
+ * (+ b_hh for LSTM, whose two biases always appear as a sum) in the same order. */
+int tad_rnn_pack_input(int cell, int64_t H, int64_t in_dim, int nblk, const float* w_ih, const float* b_ih,
+                       const float* b_hh, void* w_gl, int w_dtype, int64_t ld_gl, float* bias_gl, tad_stream_t stream);
 
 /* ------------------------------------------------------------------ elementwise family
  * add_noise (DIFF.py:102-118; get_gp_covariance DIFF.py:97-100 is the identity):

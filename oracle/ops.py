@@ -30,6 +30,11 @@ def silu_grad(x):
 # (round-to-nearest-even) and accumulates in the working dtype -- the documented
 # semantics of the bf16 compute mode.  Off by default (plain float products).
 _ROUND_OPERANDS = False
+# With storage rounding on as well (``with bf16_operands(storage=True):``) the per-timestep tensors of a
+# recurrent layer that the HIP path keeps in HBM as bf16 (input-side pre-activations, the gate stash read by
+# the backward, the pre-activation gradients) are rounded to bf16 where the kernels store them.  The HIP
+# path does so for a layer with an even hidden size and an input width that is a multiple of 8.
+_ROUND_STORAGE = False
 
 
 def bf16_round(a):
@@ -41,14 +46,27 @@ def bf16_round(a):
 
 
 class bf16_operands:
+    def __init__(self, storage=False):
+        self.storage = storage
+
     def __enter__(self):
-        global _ROUND_OPERANDS
-        self.prev = _ROUND_OPERANDS
-        _ROUND_OPERANDS = True
+        global _ROUND_OPERANDS, _ROUND_STORAGE
+        self.prev = (_ROUND_OPERANDS, _ROUND_STORAGE)
+        _ROUND_OPERANDS, _ROUND_STORAGE = True, self.storage
 
     def __exit__(self, *exc):
-        global _ROUND_OPERANDS
-        _ROUND_OPERANDS = self.prev
+        global _ROUND_OPERANDS, _ROUND_STORAGE
+        _ROUND_OPERANDS, _ROUND_STORAGE = self.prev
+
+
+def rnn_store_bf16(H, in_dim):
+    """True if a recurrent layer of this shape keeps its per-timestep tensors as bf16 (see above)."""
+    return _ROUND_STORAGE and H % 2 == 0 and in_dim % 8 == 0
+
+
+def stored(a, as_bf16):
+    """The value a tensor has after a trip through its HBM storage type."""
+    return bf16_round(a).astype(a.dtype) if as_bf16 else a
 
 
 def mm(a, b):

@@ -7,7 +7,7 @@ GRU), which is what the reference's ``nn.LSTM`` (DIFF.py:182) and ``nn.GRU``
 """
 import numpy as np
 
-from .ops import mm, sigmoid
+from .ops import mm, rnn_store_bf16, sigmoid, stored
 
 
 def _sfx(layer, reverse):
@@ -19,7 +19,8 @@ def lstm_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
     B, T, _ = x.shape
     H = Whh.shape[1]
     dt = x.dtype
-    xp = mm(x, Wih.T) + bih + bhh
+    s16 = rnn_store_bf16(H, x.shape[-1])
+    xp = stored(mm(x, Wih.T) + (bih + bhh), s16)
     h = np.zeros((B, H), dt)
     c = np.zeros((B, H), dt)
     hs = np.zeros((B, T, H), dt)
@@ -36,7 +37,7 @@ def lstm_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
         h = o * np.tanh(c)
         hs[:, t] = h
         cs[:, t] = c
-        gates[:, t] = np.concatenate([i, f, g, o], -1)
+        gates[:, t] = stored(np.concatenate([i, f, g, o], -1), s16)     # the backward reads the stored values
     return hs, (x, hs, cs, gates, reverse)
 
 
@@ -44,6 +45,7 @@ def lstm_dir_bwd(Wih, Whh, cache, dhs, need_dx=True):
     x, hs, cs, gates, reverse = cache
     B, T, H = hs.shape
     dt = x.dtype
+    s16 = rnn_store_bf16(H, x.shape[-1])
     da = np.zeros((B, T, 4 * H), dt)
     hprev_all = np.zeros((B, T, H), dt)
     dh_next = np.zeros((B, H), dt)
@@ -67,7 +69,7 @@ def lstm_dir_bwd(Wih, Whh, cache, dhs, need_dx=True):
         dg = dc * i
         df = dc * c_prev
         dc_next = dc * f
-        da_t = np.concatenate([di * i * (1 - i), df * f * (1 - f), dg * (1 - g * g), do * o * (1 - o)], -1)
+        da_t = stored(np.concatenate([di * i * (1 - i), df * f * (1 - f), dg * (1 - g * g), do * o * (1 - o)], -1), s16)
         da[:, t] = da_t
         dh_next = mm(da_t, Whh)
     da2 = da.reshape(B * T, 4 * H)
@@ -83,7 +85,8 @@ def gru_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
     B, T, _ = x.shape
     H = Whh.shape[1]
     dt = x.dtype
-    xp = mm(x, Wih.T) + bih
+    s16 = rnn_store_bf16(H, x.shape[-1])
+    xp = stored(mm(x, Wih.T) + bih, s16)
     h = np.zeros((B, H), dt)
     hs = np.zeros((B, T, H), dt)
     stash = np.zeros((B, T, 4 * H), dt)       # r, z, n, hp_n
@@ -95,7 +98,7 @@ def gru_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
         n = np.tanh(xp[:, t, 2 * H:] + r * hp[:, 2 * H:])
         h = (1 - z) * n + z * h
         hs[:, t] = h
-        stash[:, t] = np.concatenate([r, z, n, hp[:, 2 * H:]], -1)
+        stash[:, t] = stored(np.concatenate([r, z, n, hp[:, 2 * H:]], -1), s16)
     return hs, (x, hs, stash, reverse)
 
 
@@ -103,6 +106,7 @@ def gru_dir_bwd(Wih, Whh, cache, dhs, need_dx=True):
     x, hs, stash, reverse = cache
     B, T, H = hs.shape
     dt = x.dtype
+    s16 = rnn_store_bf16(H, x.shape[-1])
     dxp = np.zeros((B, T, 3 * H), dt)
     dhp = np.zeros((B, T, 3 * H), dt)
     hprev_all = np.zeros((B, T, H), dt)
@@ -123,8 +127,8 @@ def gru_dir_bwd(Wih, Whh, cache, dhs, need_dx=True):
         dan = dn * (1 - n * n)
         dar = dan * hpn * r * (1 - r)
         daz = dz * z * (1 - z)
-        dxp[:, t] = np.concatenate([dar, daz, dan], -1)
-        dhp_t = np.concatenate([dar, daz, dan * r], -1)
+        dxp[:, t] = stored(np.concatenate([dar, daz, dan], -1), s16)
+        dhp_t = stored(np.concatenate([dar, daz, dan * r], -1), s16)
         dhp[:, t] = dhp_t
         dh_next = dh * z + mm(dhp_t, Whh)
     dxp2 = dxp.reshape(B * T, 3 * H)

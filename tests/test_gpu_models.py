@@ -93,7 +93,7 @@ def test_denoiser_vs_reference_golden(dev, name, dtype):
         # (a) against the oracle with the SAME rounding points (operands of every matrix product
         # rounded to bf16, fp32 accumulation): only accumulation order and rare rounding flips differ
         _, alphas = oops.schedule(100)
-        with oops.bf16_operands():
+        with oops.bf16_operands(storage=True):
             oloss, opred, ograds = oden.loss_and_grads(sd, data["latent"], z["t"], z["i_idx"], z["noise"], data["time_info"],
                                                        data["cond"], sch, alphas)
         assert fu.rel_err(pred, opred) < BF16_EMU_TOL
@@ -206,7 +206,7 @@ def test_vae_vs_reference_golden(dev, name, dtype):
         ot, gt, gr = TOL, TOL, gref
     else:
         # the oracle with operands rounded to bf16 at the same points as the kernels
-        with oops.bf16_operands():
+        with oops.bf16_operands(storage=True):
             ototal, ores, ograds = ovae.loss_and_grads(sd, data["response"] + data["cond"], data["mask"], data["cond"], z["eps"],
                                                        np.float32(beta), sch)
         ref = dict(mu=ores["mu"], lv=ores["lv"], z=ores["z"], loss=ototal, kld=ores["parts"]["kld"],

@@ -147,92 +147,191 @@ def test_colsum(ops, dev):
     assert fu.rel_err(ow.cpu().numpy(), (dY[:, :N].astype(np.float64) * s[:, None]).sum(0) * 0.01) < F32_TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(5, 8, 8), (130, 72, 40), (257, 200, 16), (100, 800, 200), (300, 128, 448), (4100, 1600, 400)])
+def test_linear_b16_family(ops, dev, M, N, K):
+    """The three products with bf16-stored operands: exact products of the stored bf16 values, fp32 accumulation."""
+    rng = np.random.default_rng(M + 3 * N + K)
+    X = rnd(rng, M, K)
+    W16 = torch.from_numpy(rnd(rng, N, K, scale=0.3)).bfloat16()
+    b = rnd(rng, N)
+    Xd, Wd = D(X, dev), W16.to(dev)
+    Wf = W16.float().numpy().astype(np.float64)
+    ref = bf16_round(X).astype(np.float64) @ Wf.T + b
+    # forward: fp32 result, then bf16 result (+ relu)
+    Y = torch.zeros(M, N + 8, device=dev)
+    ops.linear_fwd_b16(Xd, Wd, D(b, dev), Y[:, :N])
+    assert fu.rel_err(Y[:, :N].cpu().numpy(), ref) < F32_TOL
+    assert float(Y[:, N:].abs().max()) == 0.0
+    Y16 = torch.zeros(M, N + 8, dtype=torch.bfloat16, device=dev)
+    ops.linear_fwd_b16(Xd, Wd, D(b, dev), Y16[:, :N], act=ops.ACT_RELU)
+    got, want = Y16[:, :N].float().cpu().numpy(), np.maximum(ref, 0)
+    # one bf16 rounding of the result: at most half a unit in the last of 8 significant bits (2^-8 relative)
+    # (plus the fp32 accumulation noise of the unrounded sum, which matters where the terms cancel)
+    assert np.all(np.abs(got - want) <= np.abs(want) * 2.0 ** -8 + 1e-5 * np.abs(want).max())
+    assert float(Y16[:, N:].float().abs().max()) == 0.0
+    # backward wrt the input: bf16 gradient x bf16 weights
+    dY16 = torch.from_numpy(rnd(rng, M, N)).bfloat16().to(dev)
+    dYf = dY16.float().cpu().numpy().astype(np.float64)
+    act = rnd(rng, M, K)
+    dX = torch.zeros(M, K + 4, device=dev)
+    ops.linear_bwd_data_b16(dY16, Wd, dX[:, :K], relu_of=D(act, dev))
+    assert fu.rel_err(dX[:, :K].cpu().numpy(), (dYf @ Wf) * (act > 0)) < F32_TOL
+    dX.fill_(2.0)
+    ops.linear_bwd_data_b16(dY16, Wd, dX[:, :K], accumulate=True)
+    assert fu.rel_err(dX[:, :K].cpu().numpy(), dYf @ Wf + 2.0) < F32_TOL
+    assert float((dX[:, K:] - 2.0).abs().max()) == 0.0
+    # backward wrt the weight: bf16 gradient x fp32 activations, bias sums over the bf16 values
+    dW = torch.full((N, K), 0.25, device=dev)
+    db, db2 = torch.full((N,), 0.5, device=dev), torch.full((N,), -1.0, device=dev)
+    ops.linear_bwd_weight(1, dY16, Xd, dW, db=db, db2=db2)
+    assert fu.rel_err(dW.cpu().numpy(), dYf.T @ bf16_round(X).astype(np.float64) + 0.25) < F32_TOL
+    assert fu.rel_err(db.cpu().numpy(), dYf.sum(0) + 0.5) < F32_TOL
+    assert fu.rel_err(db2.cpu().numpy(), dYf.sum(0) - 1.0) < F32_TOL
+
+
+@pytest.mark.parametrize("b16", [False, True])
+@pytest.mark.parametrize("G,slots", [(4, (0, 1, 2, 3)), (3, (0, 1, 2, -1)), (3, (0, 1, -1, 2))])
+def test_linear_bwd_weight_gate_map(ops, dev, b16, G, slots):
+    """Gate-interleaved gradient columns land in torch's gate-major rows (dropped slots contribute nothing)."""
+    rng = np.random.default_rng(17 + G)
+    M, H, K, nblk = 520, 50, 24, 2
+    dY = rnd(rng, M, nblk * 4 * H)
+    X = rnd(rng, M, K)
+    dYd = D(dY, dev).bfloat16() if b16 else D(dY, dev)
+    prec = 1 if b16 else 0
+    dYr = dYd.float().cpu().numpy().astype(np.float64)
+    Xr = (bf16_round(X) if b16 else X).astype(np.float64)
+    full = dYr.T @ Xr                                    # [nblk*4H, K], rows blk*4H + 4u + s
+    ref = np.zeros((nblk * G * H, K))
+    refb = np.zeros(nblk * G * H)
+    for blk in range(nblk):
+        for s_, g in enumerate(slots):
+            if g < 0:
+                continue
+            src = blk * 4 * H + 4 * np.arange(H) + s_
+            ref[blk * G * H + g * H + np.arange(H)] = full[src]
+            refb[blk * G * H + g * H + np.arange(H)] = dYr[:, src].sum(0)
+    dW = torch.zeros(nblk * G * H, K, device=dev)
+    db = torch.zeros(nblk * G * H, device=dev)
+    ops.linear_bwd_weight(prec, dYd, D(X, dev), dW, db=db, gate_map=(H, G, slots))
+    assert fu.rel_err(dW.cpu().numpy(), ref) < F32_TOL
+    assert fu.rel_err(db.cpu().numpy(), refb) < F32_TOL
+
+
 # ------------------------------------------------------------------ recurrent family
-def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng):
-    """Runs fwd+bwd of one layer with len(rev_flags) directions; returns device results and oracle results."""
-    kind = "lstm" if cell == 0 else "gru"
+IN_SLOTS = {0: (0, 1, 2, 3), 1: (0, 1, 2, -1)}
+HID_SLOTS = {0: (0, 1, 2, 3), 1: (0, 1, -1, 2)}
+
+
+def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11):
+    """One layer, len(rev_flags) directions sharing the input, through the C ABI exactly as the engine drives
+    it: pack -> input GEMM -> sequence kernel -> BPTT kernel -> weight / bias / input gradients.  bf16 storage
+    of the per-timestep tensors is used when the shapes allow it (H even, IN a multiple of 8).
+    Returns device results (numpy, torch's gate-major order) and the oracle's."""
     G = 4 if cell == 0 else 3
-    S = 5 if cell == 0 else 4
     nd = len(rev_flags)
-    IN = 11
+    s16 = bool(prec) and H % 2 == 0 and IN % 8 == 0
+    sdt = torch.bfloat16 if s16 else torch.float32
+    BT, H4, GH = B * T, 4 * H, G * H
     x = rnd(rng, B, T, IN)
-    out = torch.zeros(B * T, nd * H, device=dev)
-    xproj = torch.zeros(B * T, nd * G * H, device=dev)
-    stash = torch.zeros(nd, B * T, S * H, device=dev)
-    dg = torch.zeros(B * T, nd * G * H, device=dev)
-    dgh = torch.zeros(B * T, nd * G * H, device=dev) if cell == 1 else None
     dout = rnd(rng, B, T, nd * H)
+    k = 1.0 / np.sqrt(H)
+    Wih = rng.uniform(-k, k, (nd, GH, IN)).astype(np.float32)
+    Whh = rng.uniform(-k, k, (nd, GH, H)).astype(np.float32)
+    bih = rng.uniform(-k, k, (nd, GH)).astype(np.float32)
+    bhh = rng.uniform(-k, k, (nd, GH)).astype(np.float32)
+    oracle = []
+    fwd, bwd = (ornn.lstm_dir_fwd, ornn.lstm_dir_bwd) if cell == 0 else (ornn.gru_dir_fwd, ornn.gru_dir_bwd)
+    with (oops.bf16_operands(storage=True) if prec else contextlib.nullcontext()):
+        for d, rev in enumerate(rev_flags):
+            f64 = lambda a: a.astype(np.float64)
+            hs, cache = fwd(f64(x), f64(Wih[d]), f64(Whh[d]), f64(bih[d]), f64(bhh[d]), rev)
+            dx, dWih, dWhh, dbih, dbhh = bwd(f64(Wih[d]), f64(Whh[d]), cache, f64(dout[..., d * H:(d + 1) * H]))
+            oracle.append(dict(hs=hs, cache=cache, dWih=dWih, dWhh=dWhh, dbih=dbih, dbhh=dbhh, dx=dx))
+    # device
+    xd, doutd = D(x, dev).view(BT, IN), D(dout, dev).view(BT, nd * H)
+    Wihd, Whhd, bihd, bhhd = D(Wih, dev), D(Whh, dev), D(bih, dev), D(bhh, dev)
+    w_gl = torch.empty(nd * H4, IN, dtype=sdt, device=dev)
+    bias_gl = torch.empty(nd * H4, device=dev)
+    ops.rnn_pack_input(cell, H, Wihd.view(nd * GH, IN), bihd.view(-1), bhhd.view(-1), w_gl, bias_gl)
+    xproj = torch.zeros(BT, nd * H4, dtype=sdt, device=dev)
+    if s16:
+        ops.linear_fwd_b16(xd, w_gl, bias_gl, xproj)
+    else:
+        ops.linear_fwd(prec, xd, w_gl, bias_gl, xproj)
+    out = torch.zeros(BT, nd * H, device=dev)
+    gates = torch.zeros(BT, nd * H4, dtype=sdt, device=dev)
+    cst = torch.zeros(BT, nd * H, device=dev)
+    dg = torch.zeros(BT, nd * H4, dtype=sdt, device=dev)
     nbytes = ops.rnn_packed_bytes(prec, H, G)
-    fdirs, bdirs, oracle = [], [], []
-    keep = []
+    pf = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(nd)]
+    pb = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(nd)]
+    fdirs, bdirs = [], []
     for d, rev in enumerate(rev_flags):
-        k = 1.0 / np.sqrt(H)
-        Wih = (rng.uniform(-k, k, (G * H, IN))).astype(np.float32)
-        Whh = (rng.uniform(-k, k, (G * H, H))).astype(np.float32)
-        bih = (rng.uniform(-k, k, G * H)).astype(np.float32)
-        bhh = (rng.uniform(-k, k, G * H)).astype(np.float32)
-        fwd, bwd = (ornn.lstm_dir_fwd, ornn.lstm_dir_bwd) if cell == 0 else (ornn.gru_dir_fwd, ornn.gru_dir_bwd)
-        with (oops.bf16_operands() if prec else contextlib.nullcontext()):
-            hs, cache = fwd(x.astype(np.float64), Wih.astype(np.float64), Whh.astype(np.float64), bih.astype(np.float64),
-                            bhh.astype(np.float64), rev)
-            dx, dWih, dWhh, dbih, dbhh = bwd(Wih.astype(np.float64), Whh.astype(np.float64), cache,
-                                             dout[..., d * H:(d + 1) * H].astype(np.float64))
-        oracle.append(dict(hs=hs, cache=cache, dWih=dWih, dWhh=dWhh, dbih=dbih, dbhh=dbhh, dx=dx, Wih=Wih))
-        # device: input projection through the GEMM entry point in the same precision
-        Wd, Whd = D(Wih, dev), D(Whh, dev)
-        ops.linear_fwd(prec, D(x, dev).view(B * T, IN), Wd, D(bih, dev), xproj[:, d * G * H:(d + 1) * G * H],
-                       bias2=D(bhh, dev) if cell == 0 else None)
-        pf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        pb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        ops.rnn_pack_weights(prec, H, G, Whd, pf, pb)
-        bh = D(bhh, dev)
-        keep += [Wd, Whd, pf, pb, bh]
-        fdirs.append(dict(xproj=xproj[:, d * G * H:(d + 1) * G * H], w_packed=pf, b_hh=bh if cell == 1 else None,
-                          out=out[:, d * H:(d + 1) * H], stash=stash[d], reverse=rev))
-        bdirs.append(dict(dout=D(dout, dev).view(B * T, nd * H)[:, d * H:(d + 1) * H], stash=stash[d],
-                          out=out[:, d * H:(d + 1) * H], w_packed_t=pb, dgates=dg[:, d * G * H:(d + 1) * G * H],
-                          dgates_h=dgh[:, d * G * H:(d + 1) * G * H] if dgh is not None else None, reverse=rev))
+        ops.rnn_pack_weights(prec, H, G, Whhd[d], pf[d], pb[d])
+        sl, hl = slice(d * H4, (d + 1) * H4), slice(d * H, (d + 1) * H)
+        fdirs.append(dict(xproj=xproj[:, sl], w_packed=pf[d], b_hh=bhhd[d] if cell == 1 else None, out=out[:, hl],
+                          gates=gates[:, sl], cstate=cst[:, hl] if cell == 0 else None, reverse=rev))
+        bdirs.append(dict(dout=doutd[:, hl], gates=gates[:, sl], cstate=cst[:, hl] if cell == 0 else None,
+                          out=out[:, hl] if cell == 1 else None, w_packed_t=pb[d], dgates=dg[:, sl], reverse=rev))
     ops.rnn_fwd(cell, prec, B, T, H, fdirs)
     ops.rnn_bwd(cell, prec, B, T, H, bdirs)
+    dWih = torch.zeros(nd * GH, IN, device=dev)
+    dbih, dbhh = torch.zeros(nd * GH, device=dev), torch.zeros(nd * GH, device=dev)
+    dWhh = torch.zeros(nd, GH, H, device=dev)
+    ops.linear_bwd_weight(prec, dg, xd, dWih, db=dbih, db2=dbhh if cell == 0 else None, gate_map=(H, G, IN_SLOTS[cell]))
+    for d, rev in enumerate(rev_flags):
+        ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], out[:, d * H:(d + 1) * H], dWhh[d],
+                              db=None if cell == 0 else dbhh[d * GH:(d + 1) * GH], T=T, tshift=1 if rev else -1,
+                              gate_map=(H, G, HID_SLOTS[cell]))
+    dx = torch.zeros(BT, IN, device=dev)
+    if s16:
+        ops.linear_bwd_data_b16(dg, w_gl, dx)
+    else:
+        ops.linear_bwd_data(prec, dg, w_gl, dx)
     torch.cuda.synchronize()
-    return dict(out=out.cpu().numpy(), stash=stash.cpu().numpy(), dg=dg.cpu().numpy(),
-                dgh=dgh.cpu().numpy() if dgh is not None else None, oracle=oracle, x=x, dout=dout, kind=kind, G=G, S=S)
+    unglue = lambda t: t.float().view(BT, nd, H, 4).permute(0, 1, 3, 2).cpu().numpy()      # -> [BT, nd, slot, H]
+    return dict(out=out.cpu().numpy(), gates=unglue(gates), cst=cst.cpu().numpy(), xproj=unglue(xproj), dg=unglue(dg),
+                dWih=dWih.view(nd, GH, IN).cpu().numpy(), dWhh=dWhh.cpu().numpy(), dbih=dbih.view(nd, GH).cpu().numpy(),
+                dbhh=dbhh.view(nd, GH).cpu().numpy(), dx=dx.cpu().numpy(), oracle=oracle, x=x, dout=dout, G=G, s16=s16)
 
 
-RNN_CASES = [(5, 6, 24), (37, 5, 40), (70, 4, 200), (33, 3, 272), (9, 4, 30)]
+def _check_rnn(r, cell, B, T, H, tol):
+    BT = B * T
+    dx_ref = 0
+    for d, o in enumerate(r["oracle"]):
+        assert fu.rel_err(r["out"][:, d * H:(d + 1) * H], o["hs"].reshape(BT, H)) < tol, ("h", d)
+        cache = o["cache"]
+        if cell == 0:
+            _, _, cs, gates, _ = cache
+            assert fu.rel_err(r["cst"][:, d * H:(d + 1) * H], cs.reshape(BT, H)) < tol, ("c", d)
+        else:
+            gates = cache[2]
+        # a bf16-stored stash may differ from the oracle's by one unit in the last place where a value sits on a
+        # rounding boundary (2^-7 relative at most)
+        gtol = 2.0 ** -7 if r["s16"] else tol
+        assert fu.rel_err(r["gates"][:, d].reshape(BT, 4 * H), gates.reshape(BT, 4 * H)) < gtol, ("gates", d)
+        assert fu.rel_err(r["dWih"][d], o["dWih"]) < 4 * tol, ("dWih", d)
+        assert fu.rel_err(r["dWhh"][d], o["dWhh"]) < 4 * tol, ("dWhh", d)
+        assert fu.rel_err(r["dbih"][d], o["dbih"]) < 4 * tol, ("dbih", d)
+        assert fu.rel_err(r["dbhh"][d], o["dbhh"]) < 4 * tol, ("dbhh", d)
+        dx_ref = dx_ref + o["dx"].reshape(BT, -1)
+    assert fu.rel_err(r["dx"], dx_ref) < 4 * tol, "dx"
+
+
+RNN_CASES = [(5, 6, 24, 11), (37, 5, 40, 16), (70, 4, 200, 24), (33, 3, 272, 11), (9, 4, 30, 8), (6, 3, 25, 8)]
 
 
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("cell", [0, 1])
-@pytest.mark.parametrize("B,T,H", RNN_CASES)
-def test_rnn_fwd_bwd(ops, dev, cell, prec, B, T, H):
+@pytest.mark.parametrize("B,T,H,IN", RNN_CASES)
+def test_rnn_fwd_bwd(ops, dev, cell, prec, B, T, H, IN):
+    """Both directions of one layer: outputs, stash, and every gradient the layer produces, against the oracle
+    (bf16: the oracle rounds the matrix operands and, where the kernels store bf16, the stored tensors)."""
     rng = np.random.default_rng(100 * cell + 10 * prec + H)
-    r = _run_rnn(ops, dev, cell, prec, B, T, H, [False, True], rng)
-    tol = F32_TOL if prec == 0 else BF16_EMU_TOL
-    G, S = r["G"], r["S"]
-    mm = oops.mm
-    ctx = oops.bf16_operands() if prec else contextlib.nullcontext()
-    with ctx:
-      for d, o in enumerate(r["oracle"]):
-        hs = o["hs"].reshape(B * T, H)
-        assert fu.rel_err(r["out"][:, d * H:(d + 1) * H], hs) < tol, ("h", d)
-        cache = o["cache"]
-        if cell == 0:
-            _, _, cs, gates, _ = cache
-            ref_stash = np.concatenate([gates.reshape(B * T, 4 * H), cs.reshape(B * T, H)], 1)
-        else:
-            ref_stash = cache[2].reshape(B * T, 4 * H)
-        assert fu.rel_err(r["stash"][d], ref_stash) < tol, ("stash", d)
-        # pre-activation gradients: compare through the weight gradients they imply (what the model uses)
-        dgd = r["dg"][:, d * G * H:(d + 1) * G * H].astype(np.float64)
-        dWih = mm(dgd.T, r["x"].reshape(B * T, -1).astype(np.float64))
-        assert fu.rel_err(dWih, o["dWih"]) < 4 * tol, ("dWih", d)
-        assert fu.rel_err(dgd.sum(0), o["dbih"]) < 4 * tol, ("dbih", d)
-        if cell == 1:
-            dghd = r["dgh"][:, d * G * H:(d + 1) * G * H].astype(np.float64)
-            assert fu.rel_err(dghd.sum(0), o["dbhh"]) < 4 * tol, ("dbhh", d)
-        dx = mm(dgd, o["Wih"].astype(np.float64))
-        assert fu.rel_err(dx, o["dx"].reshape(B * T, -1)) < 4 * tol, ("dx", d)
+    r = _run_rnn(ops, dev, cell, prec, B, T, H, [False, True], rng, IN=IN)
+    assert r["s16"] == (bool(prec) and H % 2 == 0 and IN % 8 == 0)
+    _check_rnn(r, cell, B, T, H, F32_TOL if prec == 0 else BF16_EMU_TOL)
 
 
 def test_rnn_bwd_phased_path(ops, dev):
@@ -241,27 +340,24 @@ def test_rnn_bwd_phased_path(ops, dev):
     rng = np.random.default_rng(77)
     B, T, H = 9, 3, 320
     r = _run_rnn(ops, dev, 0, 0, B, T, H, [False], rng)
-    o = r["oracle"][0]
-    assert fu.rel_err(r["out"], o["hs"].reshape(B * T, H)) < F32_TOL
-    dgd = r["dg"].astype(np.float64)
-    assert fu.rel_err(dgd.T @ r["x"].reshape(B * T, -1).astype(np.float64), o["dWih"]) < F32_TOL
-    assert fu.rel_err(dgd @ o["Wih"].astype(np.float64), o["dx"].reshape(B * T, -1)) < F32_TOL
+    _check_rnn(r, 0, B, T, H, F32_TOL)
 
 
 def test_rnn_inference_matches_training(ops, dev):
-    """stash = NULL (inference) produces the same h as the training launch."""
+    """gates = NULL (inference) produces the same h as the training launch."""
     rng = np.random.default_rng(3)
     B, T, H, G = 17, 5, 40, 4
-    xproj = D(rnd(rng, B * T, G * H), dev)
+    xproj = D(rnd(rng, B * T, 4 * H), dev)
     Whh = D(rnd(rng, G * H, H, scale=0.2), dev)
     nbytes = ops.rnn_packed_bytes(0, H, G)
     pf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     ops.rnn_pack_weights(0, H, G, Whh, pf, None)
     o1 = torch.zeros(B * T, H, device=dev)
     o2 = torch.zeros(B * T, H, device=dev)
-    st = torch.zeros(B * T, 5 * H, device=dev)
-    ops.rnn_fwd(0, 0, B, T, H, [dict(xproj=xproj, w_packed=pf, out=o1, stash=st, reverse=False)])
-    ops.rnn_fwd(0, 0, B, T, H, [dict(xproj=xproj, w_packed=pf, out=o2, stash=None, reverse=False)])
+    st = torch.zeros(B * T, 4 * H, device=dev)
+    cs = torch.zeros(B * T, H, device=dev)
+    ops.rnn_fwd(0, 0, B, T, H, [dict(xproj=xproj, w_packed=pf, out=o1, gates=st, cstate=cs, reverse=False)])
+    ops.rnn_fwd(0, 0, B, T, H, [dict(xproj=xproj, w_packed=pf, out=o2, gates=None, reverse=False)])
     assert torch.equal(o1, o2)
 
 
@@ -477,7 +573,12 @@ def test_bad_arguments_fail_loudly(ops, dev):
     from timeautodiff_amd._lib import TadError
     x = torch.zeros(4, 4, device=dev)
     with pytest.raises(TadError):
-        ops.rnn_fwd(0, 0, 4, 1, 2000, [dict(xproj=x, w_packed=x, out=x, stash=None, reverse=False)])   # H too large
+        ops.rnn_fwd(0, 0, 4, 1, 2000, [dict(xproj=x, w_packed=x, out=x, gates=None, reverse=False)])   # H too large
+    xb = torch.zeros(8, 16, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(TadError):
+        ops.rnn_fwd(0, 0, 2, 4, 4, [dict(xproj=xb, w_packed=x, out=x, gates=None, reverse=False)])     # bf16 storage in fp32 precision
+    with pytest.raises(TadError):
+        ops.linear_fwd_b16(x, torch.zeros(4, 4, dtype=torch.bfloat16, device=dev), None, x)             # K not a multiple of 8
     with pytest.raises(TadError):
         ops.linear_fwd(0, torch.zeros(4, 4), x, None, x)                                                  # host tensor
 
@@ -492,7 +593,7 @@ def test_empty_batch_is_a_no_op(ops, dev):
     st = torch.cuda.current_stream().cuda_stream
     assert lib.tad_linear_fwd(0, 0, 8, 4, x.data_ptr() or 1, 4, w.data_ptr(), 4, None, None, None, 0, y.data_ptr() or 1, 8, 0, st) == 0
     dw = torch.full((8, 4), 0.5, device=dev)
-    assert lib.tad_linear_bwd_weight(0, 0, 8, 4, y.data_ptr() or 1, 8, x.data_ptr() or 1, 4, dw.data_ptr(), 4, None, None, 0, 0, st) == 0
+    assert lib.tad_linear_bwd_weight(0, 0, 8, 4, y.data_ptr() or 1, 8, x.data_ptr() or 1, 4, dw.data_ptr(), 4, None, None, 0, 0, None, st) == 0
     assert lib.tad_linear_bwd_data(0, 0, 8, 4, y.data_ptr() or 1, 8, w.data_ptr(), 4, x.data_ptr() or 1, 4, None, 0, 0, st) == 0
     torch.cuda.synchronize()
     assert float(dw.min()) == 0.5 and float(dw.max()) == 0.5
@@ -532,8 +633,8 @@ def test_rnn_single_sequence_and_maximum_hidden_size(ops, dev, cell):
     """B = 1 (one window) and H = 1024 (the largest hidden size the sequence kernels accept), fp32."""
     rng = np.random.default_rng(5 + cell)
     r = _run_rnn(ops, dev, cell, 0, 1, 3, 24, [False, True], rng)
-    for d in range(2):
-        assert fu.rel_err(r["out"][:, d * 24:(d + 1) * 24], r["oracle"][d]["hs"].reshape(3, 24)) < F32_TOL
+    _check_rnn(r, cell, 1, 3, 24, F32_TOL)
     B, T, H = 3, 2, 1024
-    r = _run_rnn(ops, dev, cell, 1, B, T, H, [False], np.random.default_rng(11))
-    assert fu.rel_err(r["out"], r["oracle"][0]["hs"].reshape(B * T, H)) < BF16_EMU_TOL
+    r = _run_rnn(ops, dev, cell, 1, B, T, H, [False], np.random.default_rng(11), IN=16)
+    assert r["s16"]
+    _check_rnn(r, cell, B, T, H, BF16_EMU_TOL)

@@ -21,12 +21,13 @@ _f = C.c_float
 
 class RnnDir(C.Structure):
     _fields_ = [("xproj", _p), ("ld_xproj", _i64), ("w_packed", _p), ("b_hh", _p), ("out", _p), ("ld_out", _i64),
-                ("stash", _p), ("reverse", C.c_int32), ("pad_", C.c_int32)]
+                ("gates", _p), ("ld_gates", _i64), ("cstate", _p), ("ld_c", _i64), ("reverse", C.c_int32), ("pad_", C.c_int32)]
 
 
 class RnnBwdDir(C.Structure):
-    _fields_ = [("dout", _p), ("ld_dout", _i64), ("stash", _p), ("out", _p), ("ld_out", _i64), ("w_packed_t", _p),
-                ("dgates", _p), ("dgates_h", _p), ("ld_dgates", _i64), ("reverse", C.c_int32), ("pad_", C.c_int32)]
+    _fields_ = [("dout", _p), ("ld_dout", _i64), ("gates", _p), ("ld_gates", _i64), ("cstate", _p), ("ld_c", _i64),
+                ("out", _p), ("ld_out", _i64), ("w_packed_t", _p), ("dgates", _p), ("ld_dgates", _i64),
+                ("reverse", C.c_int32), ("pad_", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every function declared in include/tad_hip.h
@@ -36,10 +37,14 @@ PROTOTYPES = {
     "tad_last_kernel": (C.c_char_p, []),
     "tad_linear_fwd": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i, _p]),
     "tad_linear_bwd_data": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
-    "tad_linear_bwd_weight": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _p]),
+    "tad_linear_bwd_weight": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, C.POINTER(C.c_int32), _p]),
+    "tad_linear_fwd_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i, _i64, _i, _p]),
+    "tad_linear_bwd_data_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
+    "tad_linear_bwd_weight_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, C.POINTER(C.c_int32), _p]),
     "tad_colsum": (_i, [_i64, _i64, _p, _i64, _p, _i64, _f, _p, _p, _p, _p]),
-    "tad_rnn_fwd": (_i, [_i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p]),
-    "tad_rnn_bwd": (_i, [_i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnBwdDir), _p]),
+    "tad_rnn_fwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p]),
+    "tad_rnn_bwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnBwdDir), _p]),
+    "tad_rnn_pack_input": (_i, [_i, _i64, _i64, _i, _p, _p, _p, _p, _i, _i64, _p, _p]),
     "tad_rnn_packed_bytes": (_i64, [_i, _i64, _i]),
     "tad_rnn_pack_weights": (_i, [_i, _i64, _i, _p, _p, _p, _p]),
     "tad_add_noise": (_i, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),

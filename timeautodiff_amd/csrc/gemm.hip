@@ -1,675 +1,5 @@
-// MFMA GEMM for the nn.Linear family on gfx950: C[i,j] = sum_k A(i,k) * B(j,k).
-//
-// One kernel template serves the three products of a linear layer by describing each operand
-// as "k-contiguous" (activation rows, weight rows) or "row-contiguous" (the same memory read as
-// its transpose).  Tiles are staged global -> registers -> LDS as [row][k] images, so the MFMA
-// fragment reads are identical in all cases.
-//
-// These products are bound by the bytes and, even more, by the number of vector-memory
-// instructions a CU pushes through its memory path (a wave-wide load costs about 16 cycles of that
-// path whether it moves 4 or 16 bytes per lane), not by the matrix cores.  Hence:
-//   * every global load is 16 bytes per lane: k-contiguous operands along k, row-contiguous
-//     operands along their rows (4 rows of one k per lane, transposed in registers);
-//   * loads are unconditional (a load inside a divergent branch is waited for where the branch
-//     ends, which serialises a k-step's loads): indices are clamped into the operand and whatever
-//     must read as zero is zeroed in registers afterwards;
-//   * tiles are as wide as the accumulator file allows, so operands are re-read less often:
-//
-//   W : 128 x 512, 8 waves (2 x 4), wave tile 64 x 128 (2 x 4 accumulators of 32 x 32)   bf16
-//   S : 256 x 256, 8 waves (4 x 2), wave tile 64 x 128                                    bf16
-//   F : 128 x 256, 8 waves (2 x 4), wave tile 64 x 64                                     fp32
-//   T : 128 x 128, 4 waves (2 x 2), wave tile 64 x 64       small problems (fill the chip)
-//
-//   fp32 : v_mfma_f32_32x32x2_f32;  bf16 : v_mfma_f32_32x32x16_bf16 (operands rounded on staging)
-// LDS image of a tile: unpadded rows of 32 k (64 B in bf16, 128 B in fp32); the 16-byte chunk c of
-// row r sits at chunk position c ^ sw(r), which makes the 16-byte fragment reads conflict-free and
-// the transposing stores at most 2-way.  Two LDS buffers: the global loads of k-step t+1 are in
-// flight under the MFMAs of step t and are written to the other buffer afterwards -- one barrier
-// per step.  Tiles are handed to workgroups so that the workgroups of one XCD (blockIdx % 8 equal)
-// walk consecutive tiles with the column tile fastest: the row panel they share stays in that L2.
-#include "common.h"
-#include <stdlib.h>
-
-// Diagnostic build only (-DEXP_STAMPS): per-phase cycle counts of wave 0 of every workgroup, summed
-// into a buffer of their own that no kernel reads.
-#ifdef EXP_STAMPS
-__device__ unsigned long long g_stamps[8];
-#define STAMP(var) __builtin_amdgcn_sched_barrier(0); unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0)
-#else
-#define STAMP(var)
-#endif
-
-namespace {
-
-constexpr int BK = 32;
-
-struct GemmParams {
-  const float* A; int64_t sa_row, sa_k;
-  const float* B; int64_t sb_row, sb_k;
-  float* C; int64_t ldc;
-  int64_t M, N, K;
-  const float* bias; const float* bias2;
-  const float* relu_of; int64_t ld_relu;
-  const float* residual; int64_t ld_res;
-  float* rowsum; float* rowsum2;   // += sum_k A(i,k) (bias gradients; added by the first column tile)
-  int act, atomic;
-  int wide_epi;              // 16-byte epilogue possible (alignment of C, bias, residual, relu operand)
-  int64_t k_per_split;
-  int shiftT, shift;         // time-shifted rows of the B operand along k (see header)
-  int64_t tiles_n, ntiles;
-};
-
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  bf16_t x = (bf16_t)a, y = (bf16_t)b;
-  uint16_t ux = __builtin_bit_cast(uint16_t, x), uy = __builtin_bit_cast(uint16_t, y);
-  return (uint32_t)ux | ((uint32_t)uy << 16);
-}
-
-// ---- LDS tile image
-template <bool BF16>
-__device__ __forceinline__ int lds_sw(int row) { return BF16 ? (row >> 2) & 3 : (row >> 1) & 7; }
-// byte offset of element k (k * element size a multiple of the access size) of row `row`
-template <bool BF16>
-__device__ __forceinline__ uint32_t lds_off(int row, int k) {
-  const int byte = k * (BF16 ? 2 : 4);
-  return (uint32_t)(row * (BF16 ? 64 : 128) + ((((byte >> 4) ^ lds_sw<BF16>(row))) << 4) + (byte & 15));
-}
-
-// store n consecutive k (n * element size = 4, 8 or a multiple of 16 bytes) of one row, from fp32 registers
-template <bool BF16, int N>
-__device__ __forceinline__ void lds_store_run(unsigned char* lds, int row, int k, const float* v) {
-  if constexpr (BF16) {
-    if constexpr (N == 2) {
-      *reinterpret_cast<uint32_t*>(lds + lds_off<true>(row, k)) = pack_bf16x2(v[0], v[1]);
-    } else if constexpr (N == 4) {
-      uint2 u;
-      u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(lds + lds_off<true>(row, k)) = u;
-    } else {
-      static_assert(N % 8 == 0, "run length");
-#pragma unroll
-      for (int j = 0; j < N / 8; ++j) {
-        uint4 u;
-        u.x = pack_bf16x2(v[8 * j + 0], v[8 * j + 1]); u.y = pack_bf16x2(v[8 * j + 2], v[8 * j + 3]);
-        u.z = pack_bf16x2(v[8 * j + 4], v[8 * j + 5]); u.w = pack_bf16x2(v[8 * j + 6], v[8 * j + 7]);
-        *reinterpret_cast<uint4*>(lds + lds_off<true>(row, k + 8 * j)) = u;
-      }
-    }
-  } else {
-    if constexpr (N == 2) {
-      *reinterpret_cast<float2*>(lds + lds_off<false>(row, k)) = make_float2(v[0], v[1]);
-    } else {
-      static_assert(N % 4 == 0, "run length");
-#pragma unroll
-      for (int j = 0; j < N / 4; ++j)
-        *reinterpret_cast<float4*>(lds + lds_off<false>(row, k + 4 * j)) = make_float4(v[4 * j + 0], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-    }
-  }
-}
-
-// ---- k-contiguous operand: tile R rows x 32 k; thread -> rows tid/8 + (NT/8)*it, 4 floats at k = 4*(tid%8).
-// Addresses are a wave-uniform base (scalar registers) plus a 32-bit per-lane offset.
-// VEC: rows 16-byte aligned and the k range a multiple of 4 -> one 16-byte load per row
-template <int R, int NT, bool VEC>
-__device__ __forceinline__ void load_kc(float* reg, const float* __restrict__ P, int64_t s_row, int64_t row0,
-                                        int64_t rows, int64_t k0, int64_t kend, int tid) {
-  constexpr int ITS = R * 8 / NT;
-  static_assert(ITS >= 1 && R * 8 % NT == 0, "tile rows vs threads");
-  const int c4 = tid & 7, r = tid >> 3;
-  const int64_t krem64 = kend - k0, nrow64 = rows - row0;
-  const int krem = (int)(krem64 < BK ? krem64 : BK);
-  const int nrow1 = (int)(nrow64 < R ? nrow64 : R) - 1;
-  const float* base = P + row0 * s_row + k0;
-#pragma unroll
-  for (int it = 0; it < ITS; ++it) {
-    int row = r + (NT / 8) * it;
-    row = row < nrow1 ? row : nrow1;
-    if constexpr (VEC) {
-      const int kq = (4 * c4 + 4 <= krem) ? 4 * c4 : 0;
-      const float4 v = *reinterpret_cast<const float4*>(base + ((uint32_t)row * (uint32_t)s_row + (uint32_t)kq));
-      reg[4 * it + 0] = v.x; reg[4 * it + 1] = v.y; reg[4 * it + 2] = v.z; reg[4 * it + 3] = v.w;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kk = (4 * c4 + i < krem) ? 4 * c4 + i : 0;
-        reg[4 * it + i] = base[(uint32_t)row * (uint32_t)s_row + (uint32_t)kk];
-      }
-    }
-  }
-}
-
-template <bool BF16, int R, int NT>
-__device__ __forceinline__ void store_kc(float* reg, unsigned char* lds, int64_t k0, int64_t kend, int tid) {
-  constexpr int ITS = R * 8 / NT;
-  const int c4 = tid & 7, r = tid >> 3;
-  const int64_t krem = kend - k0;
-  if (krem < BK) {      // zero the k tail (only the last k-step of a range has one)
-#pragma unroll
-    for (int it = 0; it < ITS; ++it)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (4 * c4 + i >= (int)krem) reg[4 * it + i] = 0.f;
-  }
-#pragma unroll
-  for (int it = 0; it < ITS; ++it) lds_store_run<BF16, 4>(lds, r + (NT / 8) * it, 4 * c4, reg + 4 * it);
-}
-
-// ---- row-contiguous operand (element (row,k) at P[k*s_k + row]).
-// VEC form: thread -> 4 consecutive rows 4*(tid % (R/4)) and KPT = 8*R/NT consecutive k starting at
-// KPT*(tid / (R/4)); one 16-byte load per k (a wave reads 1 KiB of one or two k-rows).  Needs s_k and
-// the row count to be multiples of 4 and a 16-byte aligned base.  reg[4*e + i] = (row 4*rq + i, k e).
-// Scalar form: thread -> row tid % R and 32*R/NT consecutive k, one dword load each.
-// Both return the bit mask of the thread's k positions that hold real data.
-template <int R, int NT>
-__device__ __forceinline__ uint32_t load_rc4(float* reg, const float* __restrict__ P, int64_t s_k, int64_t row0,
-                                             int64_t rows, int64_t k0, int64_t kend, int tid, int shiftT, int shift) {
-  constexpr int RQ = R / 4, KG = NT / RQ, KPT = BK / KG;
-  static_assert(NT % RQ == 0 && BK % KG == 0 && KPT >= 2, "tile rows vs threads");
-  const int rq = tid % RQ;
-  const int kg = (RQ % 64 == 0) ? __builtin_amdgcn_readfirstlane(tid / RQ) : tid / RQ;
-  const int64_t nrow64 = rows - row0;
-  const int nq1 = (int)(nrow64 < R ? nrow64 : R) / 4 - 1;
-  const int rqc = rq < nq1 ? rq : nq1;
-  const int kb = kg * KPT;
-  const int64_t krem64 = kend - k0 - kb;
-  const int kl = (int)(krem64 < KPT ? krem64 : KPT);
-  int t = shiftT > 0 ? (int)((uint32_t)(k0 + kb) % (uint32_t)shiftT) : 0;    // position inside the window of shiftT rows
-  const int sh0 = shift < 0 ? shift : 0;
-  const float* base = P + row0 + (k0 + sh0) * s_k;       // offsets from here are never negative
-  uint32_t okbits = 0;
-#pragma unroll
-  for (int e = 0; e < KPT; ++e) {
-    bool ok = e < kl;
-    if (shiftT > 0) {
-      const int ts = t + shift;
-      ok = ok && ts >= 0 && ts < shiftT;
-      if (++t == shiftT) t = 0;
-    }
-    const int kk = (ok ? kb + e + shift : 0) - sh0;          // invalid positions read row k0 of P, which exists
-    const float4 v = *reinterpret_cast<const float4*>(base + ((uint32_t)kk * (uint32_t)s_k + 4u * (uint32_t)rqc));
-    reg[4 * e + 0] = v.x; reg[4 * e + 1] = v.y; reg[4 * e + 2] = v.z; reg[4 * e + 3] = v.w;
-    okbits |= ok ? (1u << e) : 0u;
-  }
-  return okbits;
-}
-
-template <bool BF16, int R, int NT>
-__device__ __forceinline__ void store_rc4(float* reg, uint32_t okbits, unsigned char* lds, int tid) {
-  constexpr int RQ = R / 4, KG = NT / RQ, KPT = BK / KG;
-  const int rq = tid % RQ, kg = tid / RQ;
-  if (okbits != (1u << KPT) - 1u) {
-#pragma unroll
-    for (int e = 0; e < KPT; ++e)
-      if (!((okbits >> e) & 1u)) { reg[4 * e + 0] = 0.f; reg[4 * e + 1] = 0.f; reg[4 * e + 2] = 0.f; reg[4 * e + 3] = 0.f; }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float v[KPT];
-#pragma unroll
-    for (int e = 0; e < KPT; ++e) v[e] = reg[4 * e + i];
-    lds_store_run<BF16, KPT>(lds, 4 * rq + i, kg * KPT, v);
-  }
-}
-
-template <int R, int NT>
-__device__ __forceinline__ uint32_t load_rc1(float* reg, const float* __restrict__ P, int64_t s_k, int64_t row0,
-                                             int64_t rows, int64_t k0, int64_t kend, int tid, int shiftT, int shift) {
-  constexpr int KPT = BK * R / NT;
-  static_assert(NT % R == 0 && R % 64 == 0 && KPT >= 4 && KPT % 4 == 0, "tile rows vs threads");
-  const int kq = (NT == R) ? 0 : __builtin_amdgcn_readfirstlane(tid / R);
-  const int64_t nrow64 = rows - row0;
-  const int nrow1 = (int)(nrow64 < R ? nrow64 : R) - 1;
-  int r = tid % R;
-  r = r < nrow1 ? r : nrow1;
-  const int64_t kb = k0 + kq * KPT;
-  int t = shiftT > 0 ? (int)((uint32_t)kb % (uint32_t)shiftT) : 0;
-  const int64_t krem64 = kend - kb;
-  const int kl = (int)(krem64 < KPT ? krem64 : KPT);
-  const float* base = P + row0;
-  uint32_t okbits = 0;
-#pragma unroll
-  for (int e = 0; e < KPT; ++e) {
-    bool ok = e < kl;
-    if (shiftT > 0) {
-      const int ts = t + shift;
-      ok = ok && ts >= 0 && ts < shiftT;
-      if (++t == shiftT) t = 0;
-    }
-    const int64_t kidx = ok ? kb + e + shift : k0;          // k0 itself is always a valid row of P
-    reg[e] = (base + kidx * s_k)[(uint32_t)r];
-    okbits |= ok ? (1u << e) : 0u;
-  }
-  return okbits;
-}
-
-template <bool BF16, int R, int NT>
-__device__ __forceinline__ void store_rc1(float* reg, uint32_t okbits, unsigned char* lds, int tid) {
-  constexpr int KPT = BK * R / NT;
-  const int r = tid % R, kq = tid / R;
-  if (okbits != (KPT == 32 ? 0xffffffffu : ((1u << (KPT & 31)) - 1u))) {
-#pragma unroll
-    for (int e = 0; e < KPT; ++e)
-      if (!((okbits >> e) & 1u)) reg[e] = 0.f;
-  }
-  lds_store_run<BF16, KPT>(lds, r, kq * KPT, reg);
-}
-
-// Epilogue of one wave tile whose first row / column is (ib, jb): accumulator (block it, jt; register r; lane)
-// holds C[ib + 32*it + acc_row32(r, lane)][jb + 32*jt + (lane & 31)].  One store instruction writes two
-// 128-byte row segments.  MODE 0: bias + activation; 1: + residual / relu mask; 2: atomic accumulation.
-// FULL: the whole wave tile lies inside the matrix (no bounds predicates).
-template <int MODE, bool FULL, int TM, int TN>
-__device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], const GemmParams& p, int64_t ib, int64_t jb, int lane) {
-  const int lr = lane & 31, half = lane >> 5;
-  const int64_t mrem64 = p.M - ib, nrem64 = p.N - jb;
-  const int mrem = (int)(mrem64 < 32 * TM ? mrem64 : 32 * TM), nrem = (int)(nrem64 < 32 * TN ? nrem64 : 32 * TN);
-  float* cbase = p.C + ib * p.ldc + jb;
-  const uint32_t ldc = (uint32_t)p.ldc;
-  const uint32_t voff = (uint32_t)(4 * half) * ldc + (uint32_t)lr;
-  // absent residual / relu operands alias C: the loads stay unconditional, their values unused
-  const bool has_res = p.residual != nullptr, has_relu = p.relu_of != nullptr;
-  const float* rbase = has_res ? p.residual + ib * p.ld_res + jb : cbase;
-  const float* ubase = has_relu ? p.relu_of + ib * p.ld_relu + jb : cbase;
-  const uint32_t ldr = has_res ? (uint32_t)p.ld_res : ldc, ldu = has_relu ? (uint32_t)p.ld_relu : ldc;
-  const uint32_t voff_r = (uint32_t)(4 * half) * ldr + (uint32_t)lr, voff_u = (uint32_t)(4 * half) * ldu + (uint32_t)lr;
-#pragma unroll
-  for (int jt = 0; jt < TN; ++jt) {
-    const int col = 32 * jt + lr;
-    const bool cok = FULL || col < nrem;
-    float bsum = 0.f;
-    if constexpr (MODE != 2) {
-      const int cc = cok ? col : 0;
-      if (p.bias) bsum += p.bias[jb + cc];
-      if (p.bias2) bsum += p.bias2[jb + cc];
-    }
-#pragma unroll
-    for (int it = 0; it < TM; ++it) {
-      float res[16], rel[16];
-      if constexpr (MODE == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rowl = 32 * it + (r & 3) + 8 * (r >> 2);
-          const bool ok = FULL || (cok && rowl + 4 * half < mrem);
-          // uniform part in the scalar base, one per-lane offset register for all elements; both parts
-          // fall back to offset 0 outside the matrix, so every lane reads an element that exists
-          const uint32_t urow = (FULL || rowl < mrem) ? (uint32_t)rowl : 0u, ucol = (FULL || 32 * jt < nrem) ? 32u * jt : 0u;
-          res[r] = (rbase + (urow * ldr + ucol))[ok ? voff_r : 0u];
-          rel[r] = (ubase + (urow * ldu + ucol))[ok ? voff_u : 0u];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rowl = 32 * it + (r & 3) + 8 * (r >> 2);
-        const bool ok = FULL || (cok && rowl + 4 * half < mrem);
-        float* c = (cbase + ((uint32_t)rowl * ldc + 32u * jt)) + voff;
-        float v = acc[it][jt][r];
-#ifdef EXP_NOSTORE
-        if (v != 12345.678f) continue;
-#endif
-        if constexpr (MODE == 2) {
-          if (ok) atomicAdd(c, v);
-        } else {
-          v += bsum;
-          if constexpr (MODE == 1) {
-            if (has_res) v += res[r];
-          }
-          if (p.act == TAD_ACT_RELU) v = fmaxf(v, 0.f);
-          if constexpr (MODE == 1) {
-            if (has_relu && !(rel[r] > 0.f)) v = 0.f;
-          }
-          if (ok) *c = v;
-        }
-      }
-    }
-  }
-}
-
-// Same epilogue with 16-byte accesses: the wave passes its accumulators through a private 32 x 64
-// fp32 staging block in LDS (the tile buffers are free once the k-loop is done) and reads them back
-// row-major, 4 consecutive columns per lane, so C, the residual and the relu operand move as 16
-// bytes per lane: a quarter of the vector-memory instructions of the dword form.  Needs N, ldc,
-// ld_res, ld_relu multiples of 4 and 16-byte aligned bases.  MODE 0 / 1 only (no wide atomics).
-template <int MODE, int TM, int TN>
-__device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[TM][TN], const GemmParams& p, int64_t ib, int64_t jb,
-                                              int lane, float* stage) {
-  static_assert(TN % 2 == 0 && MODE != 2, "column pairs");
-  const int lr = lane & 31;
-  const int rrow = lane >> 4, c4 = lane & 15;          // read-back: row rrow + 4*pass, columns 4*c4 .. 4*c4+3 of a 64-wide pair
-  const int64_t mrem64 = p.M - ib, nrem64 = p.N - jb;
-  const int mrem = (int)(mrem64 < 32 * TM ? mrem64 : 32 * TM), nrem = (int)(nrem64 < 32 * TN ? nrem64 : 32 * TN);
-  float* cbase = p.C + ib * p.ldc + jb;
-  const uint32_t ldc = (uint32_t)p.ldc;
-  const bool has_res = p.residual != nullptr, has_relu = p.relu_of != nullptr;
-  const float* rbase = has_res ? p.residual + ib * p.ld_res + jb : cbase;
-  const float* ubase = has_relu ? p.relu_of + ib * p.ld_relu + jb : cbase;
-  const uint32_t ldr = has_res ? (uint32_t)p.ld_res : ldc, ldu = has_relu ? (uint32_t)p.ld_relu : ldc;
-  const uint32_t voff = (uint32_t)rrow * ldc + 4u * c4, voff_r = (uint32_t)rrow * ldr + 4u * c4, voff_u = (uint32_t)rrow * ldu + 4u * c4;
-#pragma unroll
-  for (int jp = 0; jp < TN / 2; ++jp) {
-    const int col = 64 * jp + 4 * c4;
-    const bool cok = col < nrem;
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-      const int cc = cok ? col : 0;
-      if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + jb + cc); bsum.x += b.x; bsum.y += b.y; bsum.z += b.z; bsum.w += b.w; }
-      if (p.bias2) { const float4 b = *reinterpret_cast<const float4*>(p.bias2 + jb + cc); bsum.x += b.x; bsum.y += b.y; bsum.z += b.z; bsum.w += b.w; }
-    }
-#pragma unroll
-    for (int it = 0; it < TM; ++it) {
-#pragma unroll
-      for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) stage[acc_row32(r, lane) * 64 + 32 * j2 + lr] = acc[it][2 * jp + j2][r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      float4 res[8], rel[8];
-      if constexpr (MODE == 1) {
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-          const int rowl = 32 * it + 4 * ps;
-          const bool ok = cok && rowl + rrow < mrem;
-          const uint32_t urow = rowl < mrem ? (uint32_t)rowl : 0u, ucol = 64 * jp < nrem ? 64u * jp : 0u;
-          res[ps] = *reinterpret_cast<const float4*>((rbase + (urow * ldr + ucol)) + (ok ? voff_r : 0u));
-          rel[ps] = *reinterpret_cast<const float4*>((ubase + (urow * ldu + ucol)) + (ok ? voff_u : 0u));
-        }
-      }
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
-        const int rowl = 32 * it + 4 * ps;
-        const bool ok = cok && rowl + rrow < mrem;
-        float4 v = *reinterpret_cast<const float4*>(stage + (4 * ps + rrow) * 64 + 4 * c4);
-        v.x += bsum.x; v.y += bsum.y; v.z += bsum.z; v.w += bsum.w;
-        if constexpr (MODE == 1) {
-          if (has_res) { v.x += res[ps].x; v.y += res[ps].y; v.z += res[ps].z; v.w += res[ps].w; }
-        }
-        if (p.act == TAD_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if constexpr (MODE == 1) {
-          if (has_relu) {
-            if (!(rel[ps].x > 0.f)) v.x = 0.f;
-            if (!(rel[ps].y > 0.f)) v.y = 0.f;
-            if (!(rel[ps].z > 0.f)) v.z = 0.f;
-            if (!(rel[ps].w > 0.f)) v.w = 0.f;
-          }
-        }
-        if (ok) *reinterpret_cast<float4*>((cbase + ((uint32_t)rowl * ldc + 64u * jp)) + voff) = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
-
-template <bool BF16, bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 ? 3 : 2)) : 1)) void gemm_kernel(GemmParams p) {
-  constexpr int NT = 64 * WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
-  constexpr int ROWB = BF16 ? 64 : 128;
-  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-  constexpr int A_REGS = BM * BK / NT, B_REGS = BN * BK / NT;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it is wave-uniform
-  const int wm = wave / WN, wn = wave % WN;
-  // XCD-aware tile assignment: workgroups with equal blockIdx % 8 share an XCD (L2); give each
-  // such group a contiguous run of tiles (bijective for any tile count).
-  int64_t tile;
-  {
-    const int64_t bid = blockIdx.x, nt = p.ntiles;
-    const int64_t xcd = bid % 8, local = bid / 8, q = nt / 8, r = nt % 8;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  }
-  const int64_t tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-  const int64_t i0 = tm * BM, j0 = tn * BN;
-  const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
-  const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
-  const int nt = (int)((kend - kbeg + BK - 1) / BK);
-  if (nt <= 0) return;
-
-  // first row / column of this wave's tile; a wave whose tile lies outside the matrix only helps staging
-  const int64_t ib = i0 + 32 * TM * wm, jb = j0 + 32 * TN * wn;
-  const bool active = ib < p.M && jb < p.N;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float ra[A_REGS], rb[B_REGS];
-  // row-contiguous A only: sums over k of this thread's A rows (4 rows in the VEC form, else 1)
-  float rsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool want_rowsum = !A_KC && p.rowsum != nullptr && tn == 0;
-  uint32_t oka = 0, okb = 0;              // valid-k masks of the row-contiguous loaders
-  int64_t kcur = kbeg;                    // k origin of the tile held in ra / rb
-  auto gload = [&](int64_t k0) {
-    kcur = k0;
-    if constexpr (A_KC) load_kc<BM, NT, VEC>(ra, p.A, p.sa_row, i0, p.M, k0, kend, tid);
-    else if constexpr (VEC) oka = load_rc4<BM, NT>(ra, p.A, p.sa_k, i0, p.M, k0, kend, tid, 0, 0);
-    else oka = load_rc1<BM, NT>(ra, p.A, p.sa_k, i0, p.M, k0, kend, tid, 0, 0);
-    if constexpr (B_KC) load_kc<BN, NT, VEC>(rb, p.B, p.sb_row, j0, p.N, k0, kend, tid);
-    else if constexpr (VEC) okb = load_rc4<BN, NT>(rb, p.B, p.sb_k, j0, p.N, k0, kend, tid, p.shiftT, p.shift);
-    else okb = load_rc1<BN, NT>(rb, p.B, p.sb_k, j0, p.N, k0, kend, tid, p.shiftT, p.shift);
-  };
-  auto lstore = [&](int buf, bool count) {
-    unsigned char* As = smem + (size_t)buf * (A_BYTES + B_BYTES);
-    unsigned char* Bs = As + A_BYTES;
-    if constexpr (A_KC) store_kc<BF16, BM, NT>(ra, As, kcur, kend, tid);
-    else if constexpr (VEC) store_rc4<BF16, BM, NT>(ra, oka, As, tid);
-    else store_rc1<BF16, BM, NT>(ra, oka, As, tid);
-    if constexpr (B_KC) store_kc<BF16, BN, NT>(rb, Bs, kcur, kend, tid);
-    else if constexpr (VEC) store_rc4<BF16, BN, NT>(rb, okb, Bs, tid);
-    else store_rc1<BF16, BN, NT>(rb, okb, Bs, tid);
-    if constexpr (!A_KC) {
-      if (want_rowsum && count) {       // ra is already zeroed where k is out of range
-        if constexpr (VEC) {
-#pragma unroll
-          for (int e = 0; e < A_REGS / 4; ++e)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rsum[i] += ra[4 * e + i];
-        } else {
-#pragma unroll
-          for (int e = 0; e < A_REGS; ++e) rsum[0] += ra[e];
-        }
-      }
-    }
-  };
-
-  // Pipeline: registers hold the tile of step t+1 while step t is multiplied.  Each step first moves
-  // those registers into the idle LDS buffer, then issues the loads of step t+2 into the same
-  // registers -- they have a whole step to arrive -- then runs the MFMAs of step t.  Loads are
-  // unconditional: beyond the range they re-read its first tile, which nobody looks at.
-  STAMP(ts0);
-  gload(kbeg);
-  lstore(0, true);
-  gload(nt > 1 ? kbeg + BK : kbeg);
-  __syncthreads();
-  STAMP(ts1);
-#ifdef EXP_STAMPS
-  unsigned long long sA = 0, sB = 0, sC = 0, sD = 0, tprev = ts1;
-#endif
-  const int half = lane >> 5, lr = lane & 31;
-  // per-lane byte offsets of the fragment chunks inside a 32-row block (the swizzle only depends on lr)
-  uint32_t foff[BF16 ? 2 : 4];
-#pragma unroll
-  for (int kk = 0; kk < (BF16 ? 2 : 4); ++kk) foff[kk] = lds_off<BF16>(lr, (BF16 ? 16 : 8) * kk + (BF16 ? 8 : 4) * half);
-
-  for (int t = 0; t < nt; ++t) {
-    lstore((t + 1) & 1, t + 1 < nt);    // the other buffer: last read one barrier ago
-    STAMP(tC);
-    gload(t + 2 < nt ? kbeg + (int64_t)(t + 2) * BK : kbeg);
-    STAMP(tA);
-    const unsigned char* As = smem + (size_t)(t & 1) * (A_BYTES + B_BYTES) + (32 * TM * wm) * ROWB;
-    const unsigned char* Bs = smem + (size_t)(t & 1) * (A_BYTES + B_BYTES) + A_BYTES + (32 * TN * wn) * ROWB;
-#ifdef EXP_NOMFMA
-    if (active && p.K == 12345) {
-#else
-    if (active) {
-#endif
-      if constexpr (BF16) {
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-          bf16x8 a[TM], b[TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(As + 32 * i * ROWB + foff[kk]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bs + 32 * j * ROWB + foff[kk]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-          f32x4 a[TM], b[TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + 32 * i * ROWB + foff[kk]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + 32 * j * ROWB + foff[kk]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-    STAMP(tB);
-    __syncthreads();
-    STAMP(tD);
-#ifdef EXP_STAMPS
-    sC += tC - tprev; sA += tA - tC; sB += tB - tA; sD += tD - tB; tprev = tD;
-#endif
-  }
-  STAMP(ts2);
-
-  if constexpr (!A_KC) {
-    if (want_rowsum) {     // uniform over the workgroup
-      // several threads hold partial sums of one row: combine them through LDS (free after the last
-      // barrier of the k-loop), then one atomic per row -- every split of the reduction adds into the
-      // same few hundred addresses, so the atomics are kept as few as possible
-      constexpr int PARTS = VEC ? NT / (BM / 4) : NT / BM;
-      float* red = reinterpret_cast<float*>(smem);           // [PARTS][BM]
-      static_assert(PARTS * BM * 4 <= 2 * (A_BYTES + B_BYTES), "reduction scratch fits the tile buffers");
-      if constexpr (VEC) {
-        const int rq = tid % (BM / 4), kg = tid / (BM / 4);
-        *reinterpret_cast<float4*>(red + kg * BM + 4 * rq) = make_float4(rsum[0], rsum[1], rsum[2], rsum[3]);
-      } else {
-        red[(tid / BM) * BM + tid % BM] = rsum[0];
-      }
-      __syncthreads();
-      if (tid < BM && i0 + tid < p.M) {
-        float sum = 0.f;
-#pragma unroll
-        for (int q = 0; q < PARTS; ++q) sum += red[q * BM + tid];
-        atomicAdd(&p.rowsum[i0 + tid], sum);
-        if (p.rowsum2) atomicAdd(&p.rowsum2[i0 + tid], sum);
-      }
-      __syncthreads();
-    }
-  }
-
-  if (active && !p.atomic && p.wide_epi) {
-    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 64);
-    static_assert((NT / 64) * 32 * 64 * 4 <= 2 * (A_BYTES + B_BYTES), "staging blocks fit the tile buffers");
-    if (p.residual || p.relu_of) epilogue_wide<1>(acc, p, ib, jb, lane, stage);
-    else epilogue_wide<0>(acc, p, ib, jb, lane, stage);
-  } else if (active) {
-    const bool full = ib + 32 * TM <= p.M && jb + 32 * TN <= p.N;
-    if (p.atomic) {
-      if (full) epilogue<2, true>(acc, p, ib, jb, lane); else epilogue<2, false>(acc, p, ib, jb, lane);
-    } else if (p.residual || p.relu_of) {
-      if (full) epilogue<1, true>(acc, p, ib, jb, lane); else epilogue<1, false>(acc, p, ib, jb, lane);
-    } else {
-      if (full) epilogue<0, true>(acc, p, ib, jb, lane); else epilogue<0, false>(acc, p, ib, jb, lane);
-    }
-  }
-#ifdef EXP_STAMPS
-  {
-    STAMP(ts3);
-    if (tid == 0) {
-      atomicAdd(&g_stamps[0], ts1 - ts0); atomicAdd(&g_stamps[1], sA); atomicAdd(&g_stamps[2], sB); atomicAdd(&g_stamps[3], sC);
-      atomicAdd(&g_stamps[4], sD); atomicAdd(&g_stamps[5], ts3 - ts2); atomicAdd(&g_stamps[6], ts3 - ts0); atomicAdd(&g_stamps[7], 1ull);
-    }
-  }
-#endif
-}
-
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-// VEC: every operand can be read with 16-byte loads.  k-contiguous: 16-byte aligned rows and a
-// reduction length that is a multiple of 4; row-contiguous: 16-byte aligned k-rows and a row count
-// that is a multiple of 4.
-inline bool vec_ok(const GemmParams& p, bool a_kc, bool b_kc) {
-  bool ok = aligned16(p.A) && aligned16(p.B);
-  if (a_kc || b_kc) ok = ok && p.K % 4 == 0;
-  ok = ok && (a_kc ? p.sa_row % 4 == 0 : (p.sa_k % 4 == 0 && p.M % 4 == 0));
-  ok = ok && (b_kc ? p.sb_row % 4 == 0 : (p.sb_k % 4 == 0 && p.N % 4 == 0));
-  return ok;
-}
-
-template <bool BF16, bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
-void launch_cfg(GemmParams& p, int splits, hipStream_t s) {
-  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-  p.tiles_n = cdiv64(p.N, BN);
-  p.ntiles = cdiv64(p.M, BM) * p.tiles_n;
-  dim3 grid((unsigned)p.ntiles, 1, (unsigned)splits);
-  p.wide_epi = !p.atomic && p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && (!p.bias || aligned16(p.bias)) &&
-               (!p.bias2 || aligned16(p.bias2)) && (!p.residual || (p.ld_res % 4 == 0 && aligned16(p.residual))) &&
-               (!p.relu_of || (p.ld_relu % 4 == 0 && aligned16(p.relu_of)));
-  const bool vec = vec_ok(p, A_KC, B_KC);
-  if (vec) hipLaunchKernelGGL((gemm_kernel<BF16, A_KC, B_KC, true, WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, s, p);
-  else hipLaunchKernelGGL((gemm_kernel<BF16, A_KC, B_KC, false, WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, s, p);
-  auto tf = [](bool b) { return b ? "true" : "false"; };
-  tad_note_kernel("gemm_kernel<%s, %s, %s, %s, %d, %d, %d, %d>", tf(BF16), tf(A_KC), tf(B_KC), tf(vec), WM, WN, TM, TN);
-}
-
-enum Cfg { CFG_W, CFG_S, CFG_F, CFG_T, CFG_H };
-struct TileDim { int bm, bn; };
-inline TileDim tile_dim(Cfg c) {
-  switch (c) {
-    case CFG_W: return {128, 512};
-    case CFG_S: return {256, 256};
-    case CFG_F: return {128, 256};
-    case CFG_H: return {128, 256};
-    default: return {128, 128};
-  }
-}
-
-// Widest tile that still gives every CU a workgroup or two; split-k launches (min_wgs == 0) fill
-// the chip through the split count instead.
-inline Cfg pick_cfg(int prec, int64_t M, int64_t N, int64_t min_wgs) {
-  Cfg big = prec == TAD_BF16 ? (N > 256 ? CFG_W : CFG_S) : CFG_F;
-  static const char* force = getenv("TAD_GEMM_CFG");     // experiments: W, S, H or T for every bf16 launch
-  if (force && prec == TAD_BF16) return force[0] == 'W' ? CFG_W : force[0] == 'S' ? CFG_S : force[0] == 'H' ? CFG_H : CFG_T;
-  const TileDim d = tile_dim(big);
-  if (cdiv64(M, d.bm) * cdiv64(N, d.bn) >= min_wgs) return big;
-  return CFG_T;
-}
-
-template <bool A_KC, bool B_KC>
-int launch(int prec, Cfg cfg, GemmParams& p, int splits, hipStream_t s) {
-  if (prec == TAD_BF16) {
-    if (cfg == CFG_W) launch_cfg<true, A_KC, B_KC, 2, 4, 2, 4>(p, splits, s);
-    else if (cfg == CFG_S) launch_cfg<true, A_KC, B_KC, 4, 2, 2, 4>(p, splits, s);
-    else if (cfg == CFG_H) launch_cfg<true, A_KC, B_KC, 2, 2, 2, 4>(p, splits, s);
-    else launch_cfg<true, A_KC, B_KC, 2, 2, 2, 2>(p, splits, s);
-  } else {
-    if (cfg == CFG_F) launch_cfg<false, A_KC, B_KC, 2, 4, 2, 2>(p, splits, s);
-    else launch_cfg<false, A_KC, B_KC, 2, 2, 2, 2>(p, splits, s);
-  }
-  TAD_LAUNCH_CHECK();
-  return TAD_OK;
-}
-
-constexpr int64_t LD_MAX = 1 << 22;   // tile-local offsets are 32-bit: 256 rows * ld * 4 bytes must fit
-constexpr int64_t MIN_WGS = 384;      // 1.5 workgroups per CU before the narrow tile takes over
-
-}  // namespace
+// nn.Linear family, fp32-stored operands (either matrix-core precision): entry points over the kernel in gemm_core.h.
+#include "gemm_core.h"
 
 extern "C" int tad_linear_fwd(int prec, int64_t M, int64_t N, int64_t K, const float* X, int64_t ldx,
                               const float* W, int64_t ldw, const float* bias, const float* bias2,
@@ -689,7 +19,7 @@ extern "C" int tad_linear_fwd(int prec, int64_t M, int64_t N, int64_t K, const f
   p.C = Y; p.ldc = ldy; p.M = M; p.N = N; p.K = K;
   p.bias = bias; p.bias2 = bias2; p.act = act; p.residual = residual; p.ld_res = ld_res;
   p.k_per_split = cdiv64(K, BK) * BK;
-  return launch<true, true>(prec, pick_cfg(prec, M, N, MIN_WGS), p, 1, (hipStream_t)stream);
+  return launch<KC32, KC32>(prec, pick_cfg(prec, M, N, MIN_WGS), p, 1, (hipStream_t)stream);
 }
 
 extern "C" int tad_linear_bwd_data(int prec, int64_t M, int64_t N, int64_t K, const float* dY, int64_t ldy,
@@ -710,12 +40,12 @@ extern "C" int tad_linear_bwd_data(int prec, int64_t M, int64_t N, int64_t K, co
   p.relu_of = relu_of; p.ld_relu = ld_relu;
   if (accumulate) { p.residual = dX; p.ld_res = ldx; }
   p.k_per_split = cdiv64(N, BK) * BK;
-  return launch<true, false>(prec, pick_cfg(prec, M, K, MIN_WGS), p, 1, (hipStream_t)stream);
+  return launch<KC32, RC32>(prec, pick_cfg(prec, M, K, MIN_WGS), p, 1, (hipStream_t)stream);
 }
 
 extern "C" int tad_linear_bwd_weight(int prec, int64_t M, int64_t N, int64_t K, const float* dY, int64_t ldy,
                                      const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, float* db2,
-                                     int64_t T, int64_t tshift, tad_stream_t stream) {
+                                     int64_t T, int64_t tshift, const int32_t* gate_map, tad_stream_t stream) {
   TAD_CHECK(prec == TAD_F32 || prec == TAD_BF16, "tad_linear_bwd_weight: bad prec %d", prec);
   TAD_CHECK(M >= 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && ldw >= K, "tad_linear_bwd_weight: bad shape M=%ld N=%ld K=%ld",
             (long)M, (long)N, (long)K);
@@ -731,18 +61,10 @@ extern "C" int tad_linear_bwd_weight(int prec, int64_t M, int64_t N, int64_t K, 
   p.C = dW; p.ldc = ldw; p.M = N; p.N = K; p.K = M;
   p.atomic = 1; p.shiftT = (int)T; p.shift = T > 0 ? (int)tshift : 0;
   p.rowsum = db; p.rowsum2 = db2;
-  // Split the long reduction over about one workgroup per CU: every split adds its whole tile
-  // with float atomics (about 1.3 TB/s chip-wide), so more splits than that only add traffic.
+  TAD_CHECK(set_gate_map(p, gate_map, N), "tad_linear_bwd_weight: bad gate map (N must be a multiple of 4*H, slots < G)");
   const Cfg cfg = pick_cfg(prec, N, K, 0);
-  const TileDim d = tile_dim(cfg);
-  const int64_t tiles = cdiv64(N, d.bm) * cdiv64(K, d.bn);
-  int64_t splits = 256 / tiles;
-  const int64_t ksteps = cdiv64(M, BK);
-  if (splits > ksteps) splits = ksteps;
-  if (splits < 1) splits = 1;
-  p.k_per_split = cdiv64(ksteps, splits) * BK;
-  splits = cdiv64(M, p.k_per_split);
-  return launch<false, false>(prec, cfg, p, (int)splits, (hipStream_t)stream);
+  const int splits = plan_splits(p, cfg);
+  return launch<RC32, RC32>(prec, cfg, p, splits, (hipStream_t)stream);
 }
 
 #ifdef EXP_STAMPS

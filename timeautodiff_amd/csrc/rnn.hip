@@ -14,14 +14,6 @@
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = batch row within the tile.
 #include "common.h"
 
-// Diagnostic build only (-DEXP_STAMPS): per-phase cycle counts of wave 0, summed over workgroups and steps.
-#ifdef EXP_STAMPS
-__device__ unsigned long long g_rstamps[8];
-#define RSTAMP(var) __builtin_amdgcn_sched_barrier(0); unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0)
-#else
-#define RSTAMP(var)
-#endif
-
 namespace {
 
 constexpr int MAXDIR = 2;
@@ -130,17 +122,49 @@ __device__ __forceinline__ void lds_put(unsigned char* base, int lds_ld, int row
 }
 
 // ---------------------------------------------------------------------------
+// Gate-interleaved tensors (xproj, gate stash, dgates): the 4 slots of hidden unit u of a direction sit
+// at columns 4u .. 4u+3, as fp32 (16 bytes) or bf16 (8 bytes): one access per lane and batch row.
+template <bool ST16> struct Slots;
+template <> struct Slots<false> {
+  typedef float4 raw;
+  static constexpr int ESZ = 4;
+  static __device__ __forceinline__ raw zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ f32x4 unpack(raw v) { return f32x4{v.x, v.y, v.z, v.w}; }
+  static __device__ __forceinline__ raw pack(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+  static __device__ __forceinline__ float one(const void* base, int64_t idx) { return reinterpret_cast<const float*>(base)[idx]; }
+};
+template <> struct Slots<true> {
+  typedef uint2 raw;
+  static constexpr int ESZ = 2;
+  static __device__ __forceinline__ raw zero() { return make_uint2(0u, 0u); }
+  static __device__ __forceinline__ f32x4 unpack(raw v) {
+    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                 __uint_as_float(v.y & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ raw pack(float a, float b, float c, float d) { return make_uint2(pk2(a, b), pk2(c, d)); }
+  static __device__ __forceinline__ float one(const void* base, int64_t idx) {
+    return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[idx] << 16);
+  }
+};
+// value a bf16 store / LDS operand will hold (what the backward's recurrent product multiplies)
+__device__ __forceinline__ float bf16_rt(float v) {
+  bf16_t b = (bf16_t)v;
+  return __uint_as_float((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+
+// ---------------------------------------------------------------------------
 struct RnnFwdArgs {
   tad_rnn_dir_t d[MAXDIR];
   int B, T, H, NJ, nk, lds_ld, rpw;
 };
 
-template <int CELL, bool BF16, int JPW>
+template <int CELL, bool BF16, bool ST16, int JPW>
 __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
   constexpr int G = CELL == TAD_CELL_LSTM ? 4 : 3;
-  constexpr int S = CELL == TAD_CELL_LSTM ? 5 : 4;
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int PF = BF16 ? 4 : 2;
+  typedef Slots<ST16> SL;
+  typedef typename SL::raw raw_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const tad_rnn_dir_t d = a.d[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -168,27 +192,33 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
 
   // Addressing: row r of the tile is batch b0 + cr + 4*half with cr = (r&3) + 8*(r>>2) a
   // compile-time constant, so every access is (wave-uniform row base) + (one 32-bit per-lane
-  // offset shared by all 16 rows); lanes 0-31 / 32-63 each cover one full 128-byte line.
+  // byte offset shared by all 16 rows); lanes 0-31 / 32-63 each cover one contiguous run of a row.
   const int half = lane >> 5;
-  // input-side pre-activations of one step for chunk slot jj (the accumulator seeds)
-  auto load_xp = [&](int step_, int jj, f32x16* acc, float* xn) {
+  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(d.xproj);
+  // input-side pre-activations (all slots of the lane's unit) of one step for chunk slot jj
+  auto load_xp = [&](int step_, int jj, raw_t* raw) {
     const int tt_ = d.reverse ? T - 1 - step_ : step_;
     const int u = 32 * (wave + jj * nw) + col;
     const bool uok = u < H;
-    const int voff = (4 * half * T + tt_) * (int)d.ld_xproj + u;
+    const uint32_t voff = (uint32_t)(((4 * half * T + tt_) * (int)d.ld_xproj + 4 * u) * SL::ESZ);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cr = (r & 3) + 8 * (r >> 2);
       const bool ok = uok && (cr + 4 * half) < a.rpw && (b0 + cr + 4 * half) < a.B;
-      const float* xp = d.xproj + (b0 + cr) * (int64_t)T * d.ld_xproj;
-      if constexpr (CELL == TAD_CELL_LSTM) {
+      const unsigned char* xp = xbase + (b0 + cr) * (int64_t)T * d.ld_xproj * SL::ESZ;
+      raw[r] = ok ? *reinterpret_cast<const raw_t*>(xp + voff) : SL::zero();
+    }
+  };
+  // accumulator seeds: LSTM all four slots; GRU r, z (b_hh is added in the epilogue) and the n slot kept aside
+  auto seed = [&](const raw_t* raw, f32x16* acc, float* xn) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g][r] = ok ? xp[voff + g * H] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const f32x4 v = SL::unpack(raw[r]);
+      if constexpr (CELL == TAD_CELL_LSTM) {
+        acc[0][r] = v[0]; acc[1][r] = v[1]; acc[2][r] = v[2]; acc[3][r] = v[3];
       } else {
-        acc[0][r] = ok ? xp[voff] : 0.f;            // b_hh is added in the epilogue so that the
-        acc[1][r] = ok ? xp[voff + H] : 0.f;        // prefetched values stay untouched (in flight)
-        acc[2][r] = 0.f;
-        xn[r] = ok ? xp[voff + 2 * H] : 0.f;
+        acc[0][r] = v[0]; acc[1][r] = v[1]; acc[2][r] = 0.f;
+        xn[r] = v[2];
       }
     }
   };
@@ -196,15 +226,11 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
   // With one chunk per wave the next step's xproj is fetched right after this step's MFMAs,
   // so its HBM latency hides under the gate math, the stores and the barrier.
   constexpr bool PREFETCH = (JPW == 1);
-  f32x16 nacc[G];
-  float nxn[16];
+  raw_t nraw[16];
   if constexpr (PREFETCH) {
-    if (wave < a.NJ) load_xp(0, 0, nacc, nxn);
+    if (wave < a.NJ) load_xp(0, 0, nraw);
   }
 
-#ifdef EXP_STAMPS
-  unsigned long long stamp_prev = 0;
-#endif
   for (int step = 0; step < T; ++step) {
     const int tt = d.reverse ? T - 1 - step : step;
     const unsigned char* cur = smem + (size_t)(step & 1) * buf_bytes;
@@ -217,73 +243,57 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
         const bool uok = u < H;
         f32x16 acc[G];
         float xn[16];
-        RSTAMP(q0);
         if constexpr (PREFETCH) {
-#pragma unroll
-          for (int g = 0; g < G; ++g) acc[g] = nacc[g];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) xn[r] = nxn[r];
-#ifdef EXP_STAMPS
-          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the prefetched values have landed
-#endif
+          seed(nraw, acc, xn);
         } else {
-          load_xp(step, jj, acc, xn);
+          raw_t raw[16];
+          load_xp(step, jj, raw);
+          seed(raw, acc, xn);
         }
-        RSTAMP(q1);
         mma_stream<BF16, G, PF>(acc, cur, a.lds_ld, wp + (int64_t)j * a.nk * G * 64, a.nk, lane);
-        RSTAMP(q2);
         if constexpr (PREFETCH) {
-          if (step + 1 < T) load_xp(step + 1, 0, nacc, nxn);
+          if (step + 1 < T) load_xp(step + 1, 0, nraw);
         }
-        RSTAMP(q3);
-#ifdef EXP_STAMPS
-        if (threadIdx.x == 0) { atomicAdd(&g_rstamps[0], q1 - q0); atomicAdd(&g_rstamps[1], q2 - q1); atomicAdd(&g_rstamps[2], q3 - q2); }
-        stamp_prev = q3;
-#endif
-        const int ooff = (4 * half * T + tt) * (int)d.ld_out + u;
-        const int soff = (4 * half * T + tt) * (S * H) + u;
+        const uint32_t ooff = (uint32_t)((4 * half * T + tt) * (int)d.ld_out + u);
+        const uint32_t goff = (uint32_t)(((4 * half * T + tt) * (int)d.ld_gates + 4 * u) * SL::ESZ);
+        const uint32_t coff = (uint32_t)((4 * half * T + tt) * (int)d.ld_c + u);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cr = (r & 3) + 8 * (r >> 2);
           const int row = cr + 4 * half;
           const bool ok = uok && row < a.rpw && (b0 + row) < a.B;
-          float h;
-          float sv[S];
+          float h, cst = 0.f;
+          raw_t sv;
           if constexpr (CELL == TAD_CELL_LSTM) {
             const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
             const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
             const float c = fg * st[jj][r] + ig * gg;
             st[jj][r] = c;
             h = og * fast_tanh(c);
-            sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og; sv[4] = c;
+            cst = c;
+            sv = SL::pack(ig, fg, gg, og);
           } else {
             const float rg = fast_sigmoid(acc[0][r] + bh[jj][0]), zg = fast_sigmoid(acc[1][r] + bh[jj][1]);
             const float hpn = acc[2][r] + bh[jj][2];
             const float ng = fast_tanh(xn[r] + rg * hpn);
             h = (1.f - zg) * ng + zg * st[jj][r];
             st[jj][r] = h;
-            sv[0] = rg; sv[1] = zg; sv[2] = ng; sv[3] = hpn;
+            sv = SL::pack(rg, zg, ng, hpn);
           }
           if (!ok) h = 0.f;
           lds_put<BF16>(nxt, a.lds_ld, row, u, h);
           if (ok) {
             (d.out + (b0 + cr) * (int64_t)T * d.ld_out)[ooff] = h;
-            if (d.stash) {
-              float* sp = d.stash + (b0 + cr) * (int64_t)T * (S * H);
-#pragma unroll
-              for (int q = 0; q < S; ++q) sp[soff + q * H] = sv[q];
+            if (d.gates) {
+              unsigned char* gp = reinterpret_cast<unsigned char*>(d.gates) + (b0 + cr) * (int64_t)T * d.ld_gates * SL::ESZ;
+              *reinterpret_cast<raw_t*>(gp + goff) = sv;
+              if constexpr (CELL == TAD_CELL_LSTM) (d.cstate + (b0 + cr) * (int64_t)T * d.ld_c)[coff] = cst;
             }
           }
         }
       }
     }
-#ifdef EXP_STAMPS
-    { RSTAMP(q4); if (threadIdx.x == 0) atomicAdd(&g_rstamps[3], q4 - stamp_prev); stamp_prev = q4; }
-#endif
     __syncthreads();
-#ifdef EXP_STAMPS
-    { RSTAMP(q5); if (threadIdx.x == 0) { atomicAdd(&g_rstamps[4], q5 - stamp_prev); atomicAdd(&g_rstamps[7], 1ull); } }
-#endif
   }
 }
 
@@ -293,11 +303,12 @@ struct RnnBwdArgs {
   int B, T, H, NJ, width, lds_ld, nk_total, nk_gate, rpw;
 };
 
-template <int CELL, bool BF16, int JPW, bool PHASED>
+template <int CELL, bool BF16, bool ST16, int JPW, bool PHASED>
 __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
   constexpr int G = CELL == TAD_CELL_LSTM ? 4 : 3;
-  constexpr int S = CELL == TAD_CELL_LSTM ? 5 : 4;
   constexpr int PF = BF16 ? 4 : 2;
+  typedef Slots<ST16> SL;
+  typedef typename SL::raw raw_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const tad_rnn_bwd_dir_t d = a.d[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -305,7 +316,6 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
   const int64_t b0 = (int64_t)blockIdx.x * a.rpw;   // rows >= rpw of the 32-row MFMA tile stay empty
   const int H = a.H, T = a.T;
   const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed_t);
-  const float* dsrc = (CELL == TAD_CELL_GRU) ? d.dgates_h : d.dgates;   // operand of the recurrent product
   const int half = lane >> 5;
 
   f32x16 acc[JPW];
@@ -328,11 +338,12 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
         const int u = 32 * j + col;
         const bool uok = u < H;
         const int rowT = 4 * half * T;
-        const int doff = (rowT + tt) * (int)d.ld_dout + u;
-        const int soff = (rowT + tt) * (S * H) + u;
-        const int spoff = (rowT + tprev) * (S * H) + u;
-        const int ooff = (rowT + tprev) * (int)d.ld_out + u;
-        const int goff = (rowT + tt) * (int)d.ld_dgates + u;
+        const uint32_t doff = (uint32_t)((rowT + tt) * (int)d.ld_dout + u);
+        const uint32_t soff = (uint32_t)(((rowT + tt) * (int)d.ld_gates + 4 * u) * SL::ESZ);
+        const uint32_t coff = (uint32_t)((rowT + tt) * (int)d.ld_c + u);
+        const uint32_t cpoff = (uint32_t)((rowT + (tprev >= 0 ? tprev : 0)) * (int)d.ld_c + u);
+        const uint32_t ooff = (uint32_t)((rowT + (tprev >= 0 ? tprev : 0)) * (int)d.ld_out + u);
+        const uint32_t goff = (uint32_t)(((rowT + tt) * (int)d.ld_dgates + 4 * u) * SL::ESZ);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cr = (r & 3) + 8 * (r >> 2);
@@ -345,10 +356,14 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
           if (ok) {
             const int64_t rb = (b0 + cr) * (int64_t)T;
             const float dh = (d.dout + rb * d.ld_dout)[doff] + acc[jj][r];
-            const float* sp = d.stash + rb * (S * H);
+            const f32x4 gv = SL::unpack(*reinterpret_cast<const raw_t*>(
+                reinterpret_cast<const unsigned char*>(d.gates) + rb * d.ld_gates * SL::ESZ + soff));
+            unsigned char* dgp = reinterpret_cast<unsigned char*>(d.dgates) + rb * d.ld_dgates * SL::ESZ;
             if constexpr (CELL == TAD_CELL_LSTM) {
-              const float ig = sp[soff], fg = sp[soff + H], gg = sp[soff + 2 * H], og = sp[soff + 3 * H], c = sp[soff + 4 * H];
-              const float cprev = (tprev >= 0) ? sp[spoff + 4 * H] : 0.f;
+              const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+              const float* cp = d.cstate + rb * d.ld_c;
+              const float c = cp[coff];
+              const float cprev = (tprev >= 0) ? cp[cpoff] : 0.f;
               const float tc = fast_tanh(c);
               const float dog = dh * tc;
               const float dc = dh * og * (1.f - tc * tc) + dcs[jj][r];
@@ -357,11 +372,9 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
               da[1] = dc * cprev * fg * (1.f - fg);
               da[2] = dc * ig * (1.f - gg * gg);
               da[3] = dog * og * (1.f - og);
-              float* dg = d.dgates + rb * d.ld_dgates;
-#pragma unroll
-              for (int g = 0; g < 4; ++g) dg[goff + g * H] = da[g];
+              *reinterpret_cast<raw_t*>(dgp + goff) = SL::pack(da[0], da[1], da[2], da[3]);
             } else {
-              const float rg = sp[soff], zg = sp[soff + H], ng = sp[soff + 2 * H], hpn = sp[soff + 3 * H];
+              const float rg = gv[0], zg = gv[1], ng = gv[2], hpn = gv[3];
               const float hprev = (tprev >= 0) ? (d.out + rb * d.ld_out)[ooff] : 0.f;
               const float dn = dh * (1.f - zg);
               const float dz = dh * (hprev - ng);
@@ -369,10 +382,7 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
               const float dar = dan * hpn * rg * (1.f - rg);
               const float daz = dz * zg * (1.f - zg);
               da[0] = dar; da[1] = daz; da[2] = dan * rg;
-              float* dg = d.dgates + rb * d.ld_dgates;
-              dg[goff] = dar; dg[goff + H] = daz; dg[goff + 2 * H] = dan;
-              float* dgh = d.dgates_h + rb * d.ld_dgates;
-              dgh[goff] = dar; dgh[goff + H] = daz; dgh[goff + 2 * H] = da[2];
+              *reinterpret_cast<raw_t*>(dgp + goff) = SL::pack(dar, daz, dan, da[2]);
               nacc = dh * zg;
             }
           }
@@ -394,7 +404,9 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
       }
       __syncthreads();
     } else {
+      // the tile does not fit LDS: one gate at a time, re-read from the dgates rows this thread wrote itself
       for (int g = 0; g < G; ++g) {
+        const int slot = (CELL == TAD_CELL_GRU && g == 2) ? 3 : g;     // GRU: the hidden-side n gradient
 #pragma unroll
         for (int jj = 0; jj < JPW; ++jj) {
           const int j = wave + jj * nw;
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
               const int row = acc_row32(r, lane);
               const int64_t b = b0 + row;
               float v = 0.f;
-              if (u < H && row < a.rpw && b < a.B) v = dsrc[(b * T + tt) * d.ld_dgates + (int64_t)g * H + u];
+              if (u < H && row < a.rpw && b < a.B) v = SL::one(d.dgates, (b * T + tt) * d.ld_dgates + 4 * u + slot);
               lds_put<BF16>(smem, a.lds_ld, row, u, v);
             }
           }
@@ -421,6 +433,32 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
         __syncthreads();
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// gate-interleaved image of the input-side parameters (see tad_rnn_pack_input)
+struct PackInArgs {
+  const float* w; const float* b_ih; const float* b_hh;
+  void* w_gl; float* bias_gl;
+  int H, G, in_dim, nblk, ld_gl, w16, lstm;
+};
+
+__global__ __launch_bounds__(256) void pack_input_kernel(PackInArgs a) {
+  const int64_t rows = (int64_t)a.nblk * 4 * a.H;
+  const int64_t total = rows * a.ld_gl;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / a.ld_gl;
+    const int k = (int)(i % a.ld_gl);
+    const int s = (int)(n & 3);
+    const int64_t q = n >> 2;
+    const int64_t blk = q / a.H, u = q % a.H;
+    const int64_t src = (blk * a.G + s) * a.H + u;
+    const bool real = s < a.G;
+    const float v = (real && k < a.in_dim) ? a.w[src * a.in_dim + k] : 0.f;
+    if (a.w16) reinterpret_cast<bf16_t*>(a.w_gl)[i] = (bf16_t)v;
+    else reinterpret_cast<float*>(a.w_gl)[i] = v;
+    if (k == 0) a.bias_gl[n] = real ? (a.lstm ? a.b_ih[src] + a.b_hh[src] : a.b_ih[src]) : 0.f;
   }
 }
 
@@ -466,25 +504,26 @@ int set_lds(K kernel, size_t bytes, size_t& configured) {
   return TAD_OK;
 }
 
-template <int CELL, bool BF16, int JPW>
+template <int CELL, bool BF16, bool ST16, int JPW>
 int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-  auto k = rnn_fwd_kernel<CELL, BF16, JPW>;
+  auto k = rnn_fwd_kernel<CELL, BF16, ST16, JPW>;
   static size_t configured = 0;
   if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
-  tad_note_kernel("rnn_fwd_kernel<%d, %s, %d>", CELL, BF16 ? "true" : "false", JPW);
+  tad_note_kernel("rnn_fwd_kernel<%d, %s, %s, %d>", CELL, BF16 ? "true" : "false", ST16 ? "true" : "false", JPW);
   return TAD_OK;
 }
 
-template <int CELL, bool BF16, int JPW, bool PHASED>
+template <int CELL, bool BF16, bool ST16, int JPW, bool PHASED>
 int launch_bwd(const RnnBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-  auto k = rnn_bwd_kernel<CELL, BF16, JPW, PHASED>;
+  auto k = rnn_bwd_kernel<CELL, BF16, ST16, JPW, PHASED>;
   static size_t configured = 0;
   if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
-  tad_note_kernel("rnn_bwd_kernel<%d, %s, %d, %s>", CELL, BF16 ? "true" : "false", JPW, PHASED ? "true" : "false");
+  tad_note_kernel("rnn_bwd_kernel<%d, %s, %s, %d, %s>", CELL, BF16 ? "true" : "false", ST16 ? "true" : "false", JPW,
+                  PHASED ? "true" : "false");
   return TAD_OK;
 }
 
@@ -517,21 +556,30 @@ extern "C" int tad_rnn_pack_weights(int prec, int64_t H, int G, const float* w_h
   return TAD_OK;
 }
 
-extern "C" int tad_rnn_fwd(int cell, int prec, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
-                           tad_stream_t stream) {
+namespace {
+// typed gate-interleaved pointers: 16-byte aligned base, leading dimension a multiple of 4
+bool gl_ok(const void* p, int64_t ld, int64_t H) { return p && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0 && ld >= 4 * H; }
+}  // namespace
+
+extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir,
+                           const tad_rnn_dir_t* dirs, tad_stream_t stream) {
   TAD_CHECK(cell == TAD_CELL_LSTM || cell == TAD_CELL_GRU, "tad_rnn_fwd: bad cell %d", cell);
   TAD_CHECK(prec == TAD_F32 || prec == TAD_BF16, "tad_rnn_fwd: bad prec %d", prec);
+  TAD_CHECK(store == TAD_F32 || (store == TAD_BF16 && prec == TAD_BF16), "tad_rnn_fwd: bad store %d (bf16 storage needs prec = TAD_BF16)", store);
   TAD_CHECK(B > 0 && T > 0 && H > 0 && H <= 1024 && (ndir == 1 || ndir == 2) && dirs, "tad_rnn_fwd: bad shape B=%ld T=%ld H=%ld ndir=%d",
             (long)B, (long)T, (long)H, ndir);
   const int G = cell == TAD_CELL_LSTM ? 4 : 3;
-  const bool bf = prec == TAD_BF16;
+  const bool bf = prec == TAD_BF16, st16 = store == TAD_BF16;
   const Geom g = geom(prec, H, G);
   RnnFwdArgs a{};
   for (int i = 0; i < ndir; ++i) {
     a.d[i] = dirs[i];
-    TAD_CHECK(dirs[i].xproj && dirs[i].w_packed && dirs[i].out, "tad_rnn_fwd: null pointer in dir %d", i);
-    TAD_CHECK(dirs[i].ld_xproj >= G * H && dirs[i].ld_out >= H, "tad_rnn_fwd: bad leading dimension in dir %d", i);
-    TAD_CHECK((5 * T + 1) * (dirs[i].ld_xproj + dirs[i].ld_out + 5 * H) < (int64_t)1 << 31, "tad_rnn_fwd: T * ld too large for 32-bit lane offsets");
+    const tad_rnn_dir_t& di = dirs[i];
+    TAD_CHECK(di.xproj && di.w_packed && di.out, "tad_rnn_fwd: null pointer in dir %d", i);
+    TAD_CHECK(gl_ok(di.xproj, di.ld_xproj, H) && di.ld_out >= H, "tad_rnn_fwd: bad xproj alignment / leading dimension in dir %d", i);
+    TAD_CHECK(!di.gates || (gl_ok(di.gates, di.ld_gates, H) && (cell == TAD_CELL_GRU || (di.cstate && di.ld_c >= H))),
+              "tad_rnn_fwd: bad gate stash (alignment, leading dimension, or missing cstate) in dir %d", i);
+    TAD_CHECK((5 * T + 1) * (di.ld_xproj + di.ld_out + di.ld_gates + di.ld_c) * 4 < (int64_t)1 << 31, "tad_rnn_fwd: T * ld too large for 32-bit lane offsets");
   }
   a.B = (int)B; a.T = (int)T; a.H = (int)H; a.NJ = g.NJ; a.nk = g.nkf;
   a.rpw = rows_per_wg(B, ndir);
@@ -540,30 +588,35 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int64_t B, int64_t T, int64_t H, 
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_fwd: H=%ld needs %zu bytes of LDS in this precision (limit %zu)", (long)H, lds, LDS_LIMIT);
   dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
-#define TAD_FWD(C, BFV)                                                                  \
-  (g.jpw == 1 ? launch_fwd<C, BFV, 1>(a, grid, block, lds, s)                             \
-              : (g.jpw == 2 ? launch_fwd<C, BFV, 2>(a, grid, block, lds, s) : launch_fwd<C, BFV, 4>(a, grid, block, lds, s)))
-  if (cell == TAD_CELL_LSTM) return bf ? TAD_FWD(TAD_CELL_LSTM, true) : TAD_FWD(TAD_CELL_LSTM, false);
-  return bf ? TAD_FWD(TAD_CELL_GRU, true) : TAD_FWD(TAD_CELL_GRU, false);
+#define TAD_FWD(C, BFV, STV)                                                              \
+  (g.jpw == 1 ? launch_fwd<C, BFV, STV, 1>(a, grid, block, lds, s)                         \
+              : (g.jpw == 2 ? launch_fwd<C, BFV, STV, 2>(a, grid, block, lds, s) : launch_fwd<C, BFV, STV, 4>(a, grid, block, lds, s)))
+  if (cell == TAD_CELL_LSTM) return bf ? (st16 ? TAD_FWD(TAD_CELL_LSTM, true, true) : TAD_FWD(TAD_CELL_LSTM, true, false)) : TAD_FWD(TAD_CELL_LSTM, false, false);
+  return bf ? (st16 ? TAD_FWD(TAD_CELL_GRU, true, true) : TAD_FWD(TAD_CELL_GRU, true, false)) : TAD_FWD(TAD_CELL_GRU, false, false);
 #undef TAD_FWD
 }
 
-extern "C" int tad_rnn_bwd(int cell, int prec, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_bwd_dir_t* dirs,
-                           tad_stream_t stream) {
+extern "C" int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir,
+                           const tad_rnn_bwd_dir_t* dirs, tad_stream_t stream) {
   TAD_CHECK(cell == TAD_CELL_LSTM || cell == TAD_CELL_GRU, "tad_rnn_bwd: bad cell %d", cell);
   TAD_CHECK(prec == TAD_F32 || prec == TAD_BF16, "tad_rnn_bwd: bad prec %d", prec);
+  TAD_CHECK(store == TAD_F32 || (store == TAD_BF16 && prec == TAD_BF16), "tad_rnn_bwd: bad store %d (bf16 storage needs prec = TAD_BF16)", store);
   TAD_CHECK(B > 0 && T > 0 && H > 0 && H <= 1024 && (ndir == 1 || ndir == 2) && dirs, "tad_rnn_bwd: bad shape B=%ld T=%ld H=%ld ndir=%d",
             (long)B, (long)T, (long)H, ndir);
   const int G = cell == TAD_CELL_LSTM ? 4 : 3;
-  const bool bf = prec == TAD_BF16;
+  const bool bf = prec == TAD_BF16, st16 = store == TAD_BF16;
   const Geom g = geom(prec, H, G);
   RnnBwdArgs a{};
   for (int i = 0; i < ndir; ++i) {
     a.d[i] = dirs[i];
-    TAD_CHECK(dirs[i].dout && dirs[i].stash && dirs[i].w_packed_t && dirs[i].dgates, "tad_rnn_bwd: null pointer in dir %d", i);
-    TAD_CHECK(cell == TAD_CELL_LSTM || (dirs[i].dgates_h && dirs[i].out), "tad_rnn_bwd: GRU needs dgates_h and out (dir %d)", i);
-    TAD_CHECK(dirs[i].ld_dout >= H && (cell == TAD_CELL_LSTM || dirs[i].ld_out >= H) && dirs[i].ld_dgates >= G * H,
-              "tad_rnn_bwd: bad leading dimension in dir %d", i);
+    const tad_rnn_bwd_dir_t& di = dirs[i];
+    TAD_CHECK(di.dout && di.gates && di.w_packed_t && di.dgates, "tad_rnn_bwd: null pointer in dir %d", i);
+    TAD_CHECK(cell == TAD_CELL_GRU ? (di.out && di.ld_out >= H) : (di.cstate && di.ld_c >= H),
+              "tad_rnn_bwd: LSTM needs cstate, GRU needs out (dir %d)", i);
+    TAD_CHECK(di.ld_dout >= H && gl_ok(di.gates, di.ld_gates, H) && gl_ok(di.dgates, di.ld_dgates, H),
+              "tad_rnn_bwd: bad alignment / leading dimension in dir %d", i);
+    TAD_CHECK((5 * T + 1) * (di.ld_dout + di.ld_out + di.ld_gates + di.ld_c + di.ld_dgates) * 4 < (int64_t)1 << 31,
+              "tad_rnn_bwd: T * ld too large for 32-bit lane offsets");
   }
   const int ks = ks_of(bf);
   a.B = (int)B; a.T = (int)T; a.H = (int)H; a.NJ = g.NJ; a.width = g.width;
@@ -578,19 +631,30 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int64_t B, int64_t T, int64_t H, 
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_bwd: H=%ld needs %zu bytes of LDS (limit %zu)", (long)H, lds, LDS_LIMIT);
   dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
-#define TAD_BWD2(C, BFV, J) (phased ? launch_bwd<C, BFV, J, true>(a, grid, block, lds, s) : launch_bwd<C, BFV, J, false>(a, grid, block, lds, s))
-#define TAD_BWD(C, BFV) (g.jpw == 1 ? TAD_BWD2(C, BFV, 1) : (g.jpw == 2 ? TAD_BWD2(C, BFV, 2) : TAD_BWD2(C, BFV, 4)))
-  if (cell == TAD_CELL_LSTM) return bf ? TAD_BWD(TAD_CELL_LSTM, true) : TAD_BWD(TAD_CELL_LSTM, false);
-  return bf ? TAD_BWD(TAD_CELL_GRU, true) : TAD_BWD(TAD_CELL_GRU, false);
+#define TAD_BWD2(C, BFV, STV, J) (phased ? launch_bwd<C, BFV, STV, J, true>(a, grid, block, lds, s) : launch_bwd<C, BFV, STV, J, false>(a, grid, block, lds, s))
+#define TAD_BWD(C, BFV, STV) (g.jpw == 1 ? TAD_BWD2(C, BFV, STV, 1) : (g.jpw == 2 ? TAD_BWD2(C, BFV, STV, 2) : TAD_BWD2(C, BFV, STV, 4)))
+  if (cell == TAD_CELL_LSTM) return bf ? (st16 ? TAD_BWD(TAD_CELL_LSTM, true, true) : TAD_BWD(TAD_CELL_LSTM, true, false)) : TAD_BWD(TAD_CELL_LSTM, false, false);
+  return bf ? (st16 ? TAD_BWD(TAD_CELL_GRU, true, true) : TAD_BWD(TAD_CELL_GRU, true, false)) : TAD_BWD(TAD_CELL_GRU, false, false);
 #undef TAD_BWD
 #undef TAD_BWD2
 }
 
-#ifdef EXP_STAMPS
-// diagnostic build only: forward kernel, wave 0, summed {seed+wait, mfma stream, prefetch issue, gate math+stores, barrier, -, -, steps}
-extern "C" int tad_dbg_rnn_stamps(unsigned long long* out8, int reset) {
-  if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_rstamps), 64);
-  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_rstamps), z, 64); }
-  return 0;
+extern "C" int tad_rnn_pack_input(int cell, int64_t H, int64_t in_dim, int nblk, const float* w_ih, const float* b_ih,
+                                  const float* b_hh, void* w_gl, int w_dtype, int64_t ld_gl, float* bias_gl,
+                                  tad_stream_t stream) {
+  TAD_CHECK(cell == TAD_CELL_LSTM || cell == TAD_CELL_GRU, "tad_rnn_pack_input: bad cell %d", cell);
+  TAD_CHECK(H > 0 && H <= 1024 && in_dim > 0 && nblk > 0 && ld_gl >= in_dim && ld_gl < (1 << 22), "tad_rnn_pack_input: bad shape H=%ld in=%ld nblk=%d ld=%ld",
+            (long)H, (long)in_dim, nblk, (long)ld_gl);
+  TAD_CHECK(w_ih && b_ih && w_gl && bias_gl && (cell == TAD_CELL_GRU || b_hh), "tad_rnn_pack_input: null pointer");
+  TAD_CHECK(w_dtype == TAD_F32 || w_dtype == TAD_BF16, "tad_rnn_pack_input: bad w_dtype %d", w_dtype);
+  PackInArgs a{};
+  a.w = w_ih; a.b_ih = b_ih; a.b_hh = b_hh; a.w_gl = w_gl; a.bias_gl = bias_gl;
+  a.H = (int)H; a.G = cell == TAD_CELL_LSTM ? 4 : 3; a.in_dim = (int)in_dim; a.nblk = nblk; a.ld_gl = (int)ld_gl;
+  a.w16 = w_dtype == TAD_BF16; a.lstm = cell == TAD_CELL_LSTM;
+  const int64_t total = (int64_t)nblk * 4 * H * ld_gl;
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
 }
-#endif

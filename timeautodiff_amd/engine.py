@@ -129,21 +129,35 @@ class RnnStack:
     """Multi-layer LSTM/GRU with ``ndir`` directions ("bidir": every layer reads the
     concatenated output of all directions of the layer below, directions run
     forward/reverse in time) or independent heads ("heads": head d of layer l reads head
-    d of layer l-1, all run forward in time; layer 0 shares the input)."""
+    d of layer l-1, all run forward in time; layer 0 shares the input).
+
+    The per-timestep tensors (input-side pre-activations, gate stash, pre-activation
+    gradients) are gate-interleaved: column d*4H + 4u + s holds slot s of unit u of
+    direction d.  In bf16 precision a layer whose shapes allow 16-byte chunks (H even,
+    input width a multiple of 8) keeps them, and the gate-interleaved image of W_ih, in
+    HBM as bfloat16; otherwise they are float32."""
+
+    IN_SLOTS = {CELL_LSTM: (0, 1, 2, 3), CELL_GRU: (0, 1, 2, -1)}     # dgates slot -> gate of W_ih / b_ih
+    HID_SLOTS = {CELL_LSTM: (0, 1, 2, 3), CELL_GRU: (0, 1, -1, 2)}    # dgates slot -> gate of W_hh / b_hh
 
     def __init__(self, fp: FlatParams, cell, H, in_dim, num_layers, dir_names, mode, prec):
         self.fp, self.cell, self.H, self.in_dim, self.L, self.mode, self.prec = fp, cell, H, in_dim, num_layers, mode, prec
         self.G = 4 if cell == CELL_LSTM else 3
-        self.S = 5 if cell == CELL_LSTM else 4
         self.dir_names = dir_names              # list of (prefix, suffix_format)
         self.ndir = len(dir_names)
         self.rev = [False, True] if mode == "bidir" else [False] * self.ndir
         nbytes = ops.rnn_packed_bytes(prec, H, self.G)
         assert nbytes > 0
-        self.packed_f = [[torch.empty(nbytes, dtype=torch.uint8, device=fp.device) for _ in range(self.ndir)]
+        dev = fp.device
+        self.packed_f = [[torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.ndir)]
                          for _ in range(num_layers)]
-        self.packed_b = [[torch.empty(nbytes, dtype=torch.uint8, device=fp.device) for _ in range(self.ndir)]
+        self.packed_b = [[torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.ndir)]
                          for _ in range(num_layers)]
+        self.store = [torch.bfloat16 if (prec == BF16 and H % 2 == 0 and self.in_l(layer) % 8 == 0) else torch.float32
+                      for layer in range(num_layers)]
+        self.w_gl = [torch.empty(self.ndir * 4 * H, self.in_l(layer), dtype=self.store[layer], device=dev)
+                     for layer in range(num_layers)]
+        self.bias_gl = [torch.empty(self.ndir * 4 * H, dtype=torch.float32, device=dev) for _ in range(num_layers)]
         self._ver_f = self._ver_b = -1
 
     def name(self, kind, layer, d):
@@ -165,16 +179,23 @@ class RnnStack:
         return self.ndir * self.H if self.mode == "bidir" else self.H
 
     def pack(self, need_bwd=True):
-        """Refresh the packed W_hh images if the parameters changed since the last pack."""
+        """Refresh the kernel-side images of the parameters (W_hh fragments, gate-interleaved W_ih
+        and biases) if the parameters changed since the last pack."""
         v = self.fp.version
         do_f = self._ver_f != v
         do_b = need_bwd and self._ver_b != v
         if not (do_f or do_b):
             return
+        fp, nd, GH = self.fp, self.ndir, self.G * self.H
         for layer in range(self.L):
-            for d in range(self.ndir):
-                ops.rnn_pack_weights(self.prec, self.H, self.G, self.fp.p(self.name("weight_hh", layer, d)),
+            for d in range(nd):
+                ops.rnn_pack_weights(self.prec, self.H, self.G, fp.p(self.name("weight_hh", layer, d)),
                                      self.packed_f[layer][d] if do_f else None, self.packed_b[layer][d] if do_b else None)
+            if do_f:
+                ops.rnn_pack_input(self.cell, self.H, fp.pgroup(self.name("weight_ih", layer, 0), nd * GH, self.in_l(layer)),
+                                   fp.pgroup(self.name("bias_ih", layer, 0), 1, nd * GH).view(-1),
+                                   fp.pgroup(self.name("bias_hh", layer, 0), 1, nd * GH).view(-1), self.w_gl[layer],
+                                   self.bias_gl[layer])
         if do_f:
             self._ver_f = v
         if do_b:
@@ -183,33 +204,39 @@ class RnnStack:
     def pack_fwd_only(self):
         self.pack(need_bwd=False)
 
+    def _xproj(self, layer, x, w_gl, bias_gl, xproj):
+        if self.store[layer] == torch.bfloat16:
+            ops.linear_fwd_b16(x, w_gl, bias_gl, xproj)
+        else:
+            ops.linear_fwd(self.prec, x, w_gl, bias_gl, xproj)
+
     def forward(self, x, B, T, ws: Workspace, tag, train):
-        fp, H, G, nd, prec = self.fp, self.H, self.G, self.ndir, self.prec
+        fp, H, nd, prec = self.fp, self.H, self.ndir, self.prec
         BT = B * T
-        GH = G * H
+        H4 = 4 * H
+        lstm = self.cell == CELL_LSTM
         self._in = x
         self._B, self._T = B, T
         inp = x
         for layer in range(self.L):
-            xproj = ws.get(f"{tag}.xproj{layer}", (BT, nd * GH))
-            shared = self.mode == "bidir" or layer == 0
-            if shared:
-                w = fp.pgroup(self.name("weight_ih", layer, 0), nd * GH, self.in_l(layer))
-                b1 = fp.pgroup(self.name("bias_ih", layer, 0), 1, nd * GH)
-                b2 = fp.pgroup(self.name("bias_hh", layer, 0), 1, nd * GH) if self.cell == CELL_LSTM else None
-                ops.linear_fwd(prec, inp, w, b1, xproj, bias2=b2)
+            sdt = self.store[layer]
+            xproj = ws.get(f"{tag}.xproj{layer}", (BT, nd * H4), dtype=sdt)
+            if self.mode == "bidir" or layer == 0:
+                self._xproj(layer, inp, self.w_gl[layer], self.bias_gl[layer], xproj)
             else:
                 for d in range(nd):
-                    b2 = fp.p(self.name("bias_hh", layer, d)) if self.cell == CELL_LSTM else None
-                    ops.linear_fwd(prec, inp[:, d * H:(d + 1) * H], fp.p(self.name("weight_ih", layer, d)),
-                                   fp.p(self.name("bias_ih", layer, d)), xproj[:, d * GH:(d + 1) * GH], bias2=b2)
+                    sl = slice(d * H4, (d + 1) * H4)
+                    self._xproj(layer, inp[:, d * H:(d + 1) * H], self.w_gl[layer][sl], self.bias_gl[layer][sl], xproj[:, sl])
             out = ws.get(f"{tag}.out{layer}", (BT, nd * H))
-            stash = ws.get(f"{tag}.stash{layer}", (nd, BT, self.S * H)) if train else None
+            gates = ws.get(f"{tag}.gates{layer}", (BT, nd * H4), dtype=sdt) if train else None
+            cst = ws.get(f"{tag}.c{layer}", (BT, nd * H)) if (train and lstm) else None
             dirs = []
             for d in range(nd):
-                dirs.append(dict(xproj=xproj[:, d * GH:(d + 1) * GH], w_packed=self.packed_f[layer][d],
-                                 b_hh=fp.p(self.name("bias_hh", layer, d)) if self.cell == CELL_GRU else None,
-                                 out=out[:, d * H:(d + 1) * H], stash=stash[d] if train else None, reverse=self.rev[d]))
+                sl = slice(d * H4, (d + 1) * H4)
+                dirs.append(dict(xproj=xproj[:, sl], w_packed=self.packed_f[layer][d],
+                                 b_hh=fp.p(self.name("bias_hh", layer, d)) if not lstm else None,
+                                 out=out[:, d * H:(d + 1) * H], gates=gates[:, sl] if train else None,
+                                 cstate=cst[:, d * H:(d + 1) * H] if cst is not None else None, reverse=self.rev[d]))
             ops.rnn_fwd(self.cell, prec, B, T, H, dirs)
             inp = out
         return inp
@@ -218,50 +245,57 @@ class RnnStack:
         fp, H, G, nd, prec = self.fp, self.H, self.G, self.ndir, self.prec
         B, T = self._B, self._T
         BT = B * T
-        GH = G * H
+        GH, H4 = G * H, 4 * H
+        lstm = self.cell == CELL_LSTM
+        in_map = (H, G, self.IN_SLOTS[self.cell])
+        hid_map = (H, G, self.HID_SLOTS[self.cell])
         for layer in range(self.L - 1, -1, -1):
+            sdt = self.store[layer]
             out = ws.get(f"{tag}.out{layer}", (BT, nd * H))
-            stash = ws.get(f"{tag}.stash{layer}", (nd, BT, self.S * H))
+            gates = ws.get(f"{tag}.gates{layer}", (BT, nd * H4), dtype=sdt)
+            cst = ws.get(f"{tag}.c{layer}", (BT, nd * H)) if lstm else None
             inp = self._in if layer == 0 else ws.get(f"{tag}.out{layer - 1}", (BT, nd * H))
-            dg = ws.get(f"{tag}.dg{layer}", (BT, nd * GH))
-            dgh = ws.get(f"{tag}.dgh{layer}", (BT, nd * GH)) if self.cell == CELL_GRU else None
+            dg = ws.get(f"{tag}.dg{layer}", (BT, nd * H4), dtype=sdt)
             dirs = []
             for d in range(nd):
-                dirs.append(dict(dout=dout[:, d * H:(d + 1) * H], stash=stash[d], out=out[:, d * H:(d + 1) * H],
-                                 w_packed_t=self.packed_b[layer][d], dgates=dg[:, d * GH:(d + 1) * GH],
-                                 dgates_h=dgh[:, d * GH:(d + 1) * GH] if dgh is not None else None, reverse=self.rev[d]))
+                sl = slice(d * H4, (d + 1) * H4)
+                dirs.append(dict(dout=dout[:, d * H:(d + 1) * H], gates=gates[:, sl],
+                                 cstate=cst[:, d * H:(d + 1) * H] if lstm else None,
+                                 out=out[:, d * H:(d + 1) * H] if not lstm else None,
+                                 w_packed_t=self.packed_b[layer][d], dgates=dg[:, sl], reverse=self.rev[d]))
             ops.rnn_bwd(self.cell, prec, B, T, H, dirs)
             shared = self.mode == "bidir" or layer == 0
             in_l = self.in_l(layer)
-            # input-side weights; the bias gradients ride along as column sums of the same dgates:
-            # LSTM b_ih and b_hh both receive sum(dg); GRU b_hh receives sum(dgh) with the W_hh pass
+            # input-side weights; the bias gradients ride along as row sums of the same dgates:
+            # LSTM b_ih and b_hh both receive the sums; GRU b_hh receives the hidden-side sums with the W_hh pass
             gb_ih = fp.ggroup(self.name("bias_ih", layer, 0), 1, nd * GH).view(-1)
             gb_hh = fp.ggroup(self.name("bias_hh", layer, 0), 1, nd * GH).view(-1)
-            lstm = self.cell == CELL_LSTM
             if shared:
                 ops.linear_bwd_weight(prec, dg, inp, fp.ggroup(self.name("weight_ih", layer, 0), nd * GH, in_l),
-                                      db=gb_ih, db2=gb_hh if lstm else None)
+                                      db=gb_ih, db2=gb_hh if lstm else None, gate_map=in_map)
             else:
                 for d in range(nd):
                     sl = slice(d * GH, (d + 1) * GH)
-                    ops.linear_bwd_weight(prec, dg[:, sl], inp[:, d * H:(d + 1) * H], fp.g(self.name("weight_ih", layer, d)),
-                                          db=gb_ih[sl], db2=gb_hh[sl] if lstm else None)
+                    ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], inp[:, d * H:(d + 1) * H],
+                                          fp.g(self.name("weight_ih", layer, d)), db=gb_ih[sl], db2=gb_hh[sl] if lstm else None,
+                                          gate_map=in_map)
             # recurrent weights: dW_hh += dgates^T h_{t-1}
-            src = dg if lstm else dgh
             for d in range(nd):
-                sl = slice(d * GH, (d + 1) * GH)
-                ops.linear_bwd_weight(prec, src[:, sl], out[:, d * H:(d + 1) * H], fp.g(self.name("weight_hh", layer, d)),
-                                      db=None if lstm else gb_hh[sl], T=T, tshift=(1 if self.rev[d] else -1))
-            # gradient wrt the layer input
+                ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], out[:, d * H:(d + 1) * H],
+                                      fp.g(self.name("weight_hh", layer, d)), db=None if lstm else gb_hh[d * GH:(d + 1) * GH],
+                                      T=T, tshift=(1 if self.rev[d] else -1), gate_map=hid_map)
+            # gradient wrt the layer input (the unused slot of a GRU meets a zero row of the weight image)
             if layer > 0 or need_dx:
                 dx = ws.get(f"{tag}.dx{layer}", (BT, in_l if shared else nd * H))
                 ro = relu_of if layer == 0 else None
+                bwd_data = (lambda dy, w, o, r=None: ops.linear_bwd_data_b16(dy, w, o, relu_of=r)) if sdt == torch.bfloat16 else \
+                    (lambda dy, w, o, r=None: ops.linear_bwd_data(prec, dy, w, o, relu_of=r))
                 if shared:
-                    ops.linear_bwd_data(prec, dg, fp.pgroup(self.name("weight_ih", layer, 0), nd * GH, in_l), dx, relu_of=ro)
+                    bwd_data(dg, self.w_gl[layer], dx, ro)
                 else:
                     for d in range(nd):
-                        ops.linear_bwd_data(prec, dg[:, d * GH:(d + 1) * GH], fp.p(self.name("weight_ih", layer, d)),
-                                            dx[:, d * H:(d + 1) * H])
+                        sl = slice(d * H4, (d + 1) * H4)
+                        bwd_data(dg[:, sl], self.w_gl[layer][sl], dx[:, d * H:(d + 1) * H])
                 dout = dx
             else:
                 dout = None

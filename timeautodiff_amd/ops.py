@@ -21,10 +21,10 @@ def _chk_dev(t):
         raise _lib.TadError("libtad_hip ops need device tensors (no CPU path exists)")
 
 
-def as2d(t):
-    """(ptr, rows, cols, ld) of a float32 tensor viewed as rows x cols."""
+def as2d(t, dtype=torch.float32):
+    """(ptr, rows, cols, ld) of a float32 (or ``dtype``) tensor viewed as rows x cols."""
     _chk_dev(t)
-    assert t.dtype == torch.float32, t.dtype
+    assert t.dtype == dtype, (t.dtype, dtype)
     cols = t.shape[-1]
     assert t.stride(-1) == 1 or cols == 1, (t.shape, t.stride())
     if t.dim() == 1:
@@ -130,15 +130,60 @@ def linear_bwd_data(prec, dy, w, dx, relu_of=None, accumulate=False):
     _call("tad_linear_bwd_data", prec, M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream())
 
 
-def linear_bwd_weight(prec, dy, x, dw, db=None, db2=None, T=0, tshift=0):
-    """dw += dy^T x (time-shifted x rows if T > 0); db (and db2) += column sums of dy in the same pass."""
-    dyp, M, N, ldy = as2d(dy)
+def _gate_map(gate_map):
+    """(H, G, (slot0..slot3)) -> the host int32[6] array of the C ABI (None passes NULL)."""
+    if gate_map is None:
+        return None
+    H, G, slots = gate_map
+    return (C.c_int32 * 6)(H, G, *slots)
+
+
+def linear_bwd_weight(prec, dy, x, dw, db=None, db2=None, T=0, tshift=0, gate_map=None):
+    """dw += dy^T x (time-shifted x rows if T > 0); db (and db2) += column sums of dy in the same pass.
+    dy may be a bfloat16 tensor (bf16 precision only).  gate_map=(H, G, slots): dy is gate-interleaved
+    (column blk*4H + 4u + s) and its product rows go to torch's gate-major rows blk*G*H + slots[s]*H + u of dw/db."""
+    b16 = dy.dtype == torch.bfloat16
+    dyp, M, N, ldy = as2d(dy, dy.dtype)
     xp, Mx, K, ldx = as2d(x)
     dwp, Nw, Kw, ldw = as2d(dw)
-    assert M == Mx and N == Nw and K == Kw, (dy.shape, x.shape, dw.shape)
+    if gate_map is None:
+        n_out = N
+    else:
+        assert N % (4 * gate_map[0]) == 0, (N, gate_map)
+        n_out = N // 4 * gate_map[1]
+    assert M == Mx and n_out == Nw and K == Kw, (dy.shape, x.shape, dw.shape, gate_map)
     for b in (db, db2):
-        assert b is None or (b.is_contiguous() and b.numel() == N), (N, None if b is None else b.shape)
-    _call("tad_linear_bwd_weight", prec, M, N, K, dyp, ldy, xp, ldx, dwp, ldw, _ptr(db), _ptr(db2), T, tshift, _stream())
+        assert b is None or (b.is_contiguous() and b.numel() == n_out), (n_out, None if b is None else b.shape)
+    if b16:
+        assert prec == BF16
+        _call("tad_linear_bwd_weight_b16", M, N, K, dyp, ldy, xp, ldx, dwp, ldw, _ptr(db), _ptr(db2), T, tshift,
+              _gate_map(gate_map), _stream())
+    else:
+        _call("tad_linear_bwd_weight", prec, M, N, K, dyp, ldy, xp, ldx, dwp, ldw, _ptr(db), _ptr(db2), T, tshift,
+              _gate_map(gate_map), _stream())
+
+
+def linear_fwd_b16(x, w16, bias, y, act=ACT_NONE):
+    """y = act(x w16^T + bias): x fp32, w16 bfloat16 [N,K], y float32 or bfloat16 (bf16 matrix cores)."""
+    xp, M, K, ldx = as2d(x)
+    wp, N, Kw, ldw = as2d(w16, torch.bfloat16)
+    yp, My, Ny, ldy = as2d(y, y.dtype)
+    assert K == Kw and M == My and N == Ny, (x.shape, w16.shape, y.shape)
+    _call("tad_linear_fwd_b16", M, N, K, xp, ldx, wp, ldw, _ptr(bias), yp, BF16 if y.dtype == torch.bfloat16 else F32, ldy,
+          act, _stream())
+
+
+def linear_bwd_data_b16(dy16, w16, dx, relu_of=None, accumulate=False):
+    """dx = dy16 w16 (+ dx), masked where relu_of <= 0: dy16 bfloat16 [M,N], w16 bfloat16 [N,K], dx fp32."""
+    dyp, M, N, ldy = as2d(dy16, torch.bfloat16)
+    wp, Nw, K, ldw = as2d(w16, torch.bfloat16)
+    dxp, Mx, Kx, ldx = as2d(dx)
+    assert N == Nw and M == Mx and K == Kx, (dy16.shape, w16.shape, dx.shape)
+    rp, ldr = None, 0
+    if relu_of is not None:
+        rp, Mr, Kr, ldr = as2d(relu_of)
+        assert Mr == M and Kr == K
+    _call("tad_linear_bwd_data_b16", M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream())
 
 
 def colsum(dy, out_sum=None, out_sum2=None, row_scale=None, row_scale_stride=1, scale_mul=1.0, out_wsum=None):
@@ -157,31 +202,61 @@ def rnn_pack_weights(prec, H, G, w_hh, packed_fwd, packed_bwd):
     _call("tad_rnn_pack_weights", prec, H, G, w_hh.data_ptr(), _ptr(packed_fwd), _ptr(packed_bwd), _stream())
 
 
+def _store_of(t):
+    return BF16 if t.dtype == torch.bfloat16 else F32
+
+
+def rnn_pack_input(cell, H, w_ih, b_ih, b_hh, w_gl, bias_gl):
+    """Gate-interleaved image of the glued input-side parameters of nblk directions/heads:
+    w_ih [nblk*G*H, in] -> w_gl [nblk*4H, ld >= in] (float32 or bfloat16), bias_gl [nblk*4H]."""
+    G = 4 if cell == CELL_LSTM else 3
+    wp, rows, in_dim, ldw = as2d(w_ih)
+    assert ldw == in_dim and rows % (G * H) == 0, (w_ih.shape, w_ih.stride())
+    nblk = rows // (G * H)
+    gp, grows, gcols, ldg = as2d(w_gl, w_gl.dtype)
+    assert grows == nblk * 4 * H and gcols >= in_dim and ldg == gcols and bias_gl.numel() == nblk * 4 * H and bias_gl.is_contiguous()
+    assert b_ih.is_contiguous() and (b_hh is None or b_hh.is_contiguous())
+    _call("tad_rnn_pack_input", cell, H, in_dim, nblk, wp, b_ih.data_ptr(), _ptr(b_hh), gp, _store_of(w_gl), ldg,
+          bias_gl.data_ptr(), _stream())
+
+
 def rnn_fwd(cell, prec, B, T, H, dirs):
-    """dirs: list of dict(xproj=(tensor2d), w_packed, b_hh, out, stash, reverse)."""
+    """dirs: list of dict(xproj (2-d view, float32 or bfloat16, gate-interleaved), w_packed, b_hh, out,
+    gates (same dtype as xproj, or None = inference), cstate (LSTM training), reverse)."""
     arr = (RnnDir * len(dirs))()
+    store = _store_of(dirs[0]["xproj"])
     for k, d in enumerate(dirs):
-        xp, _, _, ldxp = as2d(d["xproj"])
+        dt = d["xproj"].dtype
+        assert _store_of(d["xproj"]) == store
+        xp, _, _, ldxp = as2d(d["xproj"], dt)
         op, _, _, ldo = as2d(d["out"])
-        arr[k] = RnnDir(xp, ldxp, d["w_packed"].data_ptr(), _ptr(d.get("b_hh")), op, ldo, _ptr(d.get("stash")),
+        gp, ldg, cp, ldc = None, 0, None, 0
+        if d.get("gates") is not None:
+            gp, _, _, ldg = as2d(d["gates"], dt)
+            if d.get("cstate") is not None:
+                cp, _, _, ldc = as2d(d["cstate"])
+        arr[k] = RnnDir(xp, ldxp, d["w_packed"].data_ptr(), _ptr(d.get("b_hh")), op, ldo, gp, ldg, cp, ldc,
                         int(d["reverse"]), 0)
-    _call("tad_rnn_fwd", cell, prec, B, T, H, len(dirs), arr, _stream())
+    _call("tad_rnn_fwd", cell, prec, store, B, T, H, len(dirs), arr, _stream())
 
 
 def rnn_bwd(cell, prec, B, T, H, dirs):
-    """dirs: list of dict(dout, stash, out, w_packed_t, dgates, dgates_h, reverse)."""
+    """dirs: list of dict(dout, gates, cstate (LSTM), out (GRU), w_packed_t, dgates, reverse)."""
     arr = (RnnBwdDir * len(dirs))()
+    store = _store_of(dirs[0]["gates"])
     for k, d in enumerate(dirs):
+        dt = d["gates"].dtype
+        assert _store_of(d["gates"]) == store and d["dgates"].dtype == dt
         dp, _, _, ldd = as2d(d["dout"])
-        op, _, _, ldo = as2d(d["out"])
-        gp, _, _, ldg = as2d(d["dgates"])
-        ghp = None
-        if d.get("dgates_h") is not None:
-            ghp, _, _, ldg2 = as2d(d["dgates_h"])
-            assert ldg2 == ldg
-        arr[k] = RnnBwdDir(dp, ldd, d["stash"].data_ptr(), op, ldo, d["w_packed_t"].data_ptr(), gp, ghp, ldg,
-                           int(d["reverse"]), 0)
-    _call("tad_rnn_bwd", cell, prec, B, T, H, len(dirs), arr, _stream())
+        sp, _, _, lds = as2d(d["gates"], dt)
+        cp, ldc, op, ldo = None, 0, None, 0
+        if d.get("cstate") is not None:
+            cp, _, _, ldc = as2d(d["cstate"])
+        if d.get("out") is not None:
+            op, _, _, ldo = as2d(d["out"])
+        gp, _, _, ldg = as2d(d["dgates"], dt)
+        arr[k] = RnnBwdDir(dp, ldd, sp, lds, cp, ldc, op, ldo, d["w_packed_t"].data_ptr(), gp, ldg, int(d["reverse"]), 0)
+    _call("tad_rnn_bwd", cell, prec, store, B, T, H, len(dirs), arr, _stream())
 
 
 # ------------------------------------------------------------------ elementwise family
