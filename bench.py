@@ -66,25 +66,6 @@ def fwd_macs_per_sample():
     return T * per_t
 
 
-def kernel_cost(key):
-    """(kind, algorithmic FLOPs, algorithmic HBM bytes) of one C-ABI call from its integer arguments."""
-    name = key[0]
-    if name in ("tad_linear_fwd", "tad_linear_bwd_data", "tad_linear_bwd_weight"):
-        _, prec, M, N, Kk = key[:5]
-        return "mfma", 2.0 * M * N * Kk, 4.0 * (M * Kk + N * Kk + M * N)
-    if name in ("tad_rnn_fwd", "tad_rnn_bwd"):
-        _, cell, prec, B, Tt, Hh, ndir = key[:7]
-        G = 4 if cell == 0 else 3
-        S = 5 if cell == 0 else 4
-        flops = 2.0 * B * Tt * ndir * G * Hh * Hh
-        if name == "tad_rnn_fwd":
-            byts = 4.0 * B * Tt * ndir * Hh * (G + 1 + S)              # xproj in, h out, stash out
-        else:
-            byts = 4.0 * B * Tt * ndir * Hh * (1 + S + 1 + G * (2 if cell else 1))   # dout, stash, c/h prev, dgates out
-        return "mfma", flops, byts
-    return "hbm", 0.0, 0.0
-
-
 def cpu_baseline(seconds_budget=20.0):
     """The numpy oracle (a port of the reference's algorithm) timed on this host: full denoiser
     training steps (forward, loss, backward, Adam) on {Bc}-window batches of the same shape."""
@@ -182,8 +163,7 @@ def main():
     kstat = {}
     for kern, calls in by_kernel.items():
         ent = kstat.setdefault(kern, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-        for key, (cnt, ms) in calls.items():
-            _, fl, by = kernel_cost(key)
+        for key, (cnt, ms, fl, by) in calls.items():
             ent["calls"] += cnt
             ent["ms"] += ms
             ent["flops"] += fl * cnt

@@ -57,6 +57,24 @@ def main():
             names = ["prologue", "load issue", "mfma", "wait+lds store", "barrier", "epilogue", "total"]
             print("  per-workgroup cycles (wave 0): " + ", ".join(f"{nm} {buf[i] / n:.0f}" for i, nm in enumerate(names)) + f"  (n={buf[7]})")
         return
+    if prec == ops.BF16 and os.environ.get("GEMM_B16", "1") == "1":
+        print("bf16-stored operands (recurrent layers' input side): fwd X fp32, W bf16 -> Y bf16; bwd_d dY bf16, W bf16; bwd_w dY bf16, X fp32")
+        for N, K in [(1600, 400), (1600, 200), (1600, 128), (800, 200)]:
+            x = torch.randn(M, K, device=dev)
+            w16 = (torch.randn(N, K, device=dev) * 0.1).bfloat16()
+            b = torch.randn(N, device=dev)
+            y16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            dx = torch.empty(M, K, device=dev)
+            dw = torch.zeros(N, K, device=dev)
+            db = torch.zeros(N, device=dev)
+            fl = 2.0 * M * N * K
+            t_f = timeit(lambda: ops.linear_fwd_b16(x, w16, b, y16))
+            t_d = timeit(lambda: ops.linear_bwd_data_b16(y16, w16, dx))
+            t_w = timeit(lambda: ops.linear_bwd_weight(prec, y16, x, dw, db=db, gate_map=(N // 8, 4, (0, 1, 2, 3))))
+            t_ws = timeit(lambda: ops.linear_bwd_weight(prec, y16, x, dw, T=24, tshift=-1)) if M % 24 == 0 else 0.0
+            by = 4.0 * M * K + 2.0 * N * K + 2.0 * M * N
+            print(f"{N:6d} {K:6d} | {t_f:8.1f} {fl / t_f / 1e6:6.1f} {by / t_f / 1e3:6.0f} | {t_d:8.1f} {fl / t_d / 1e6:6.1f} | "
+                  f"{t_w:8.1f} {fl / t_w / 1e6:6.1f} | {t_ws:8.1f}")
     for N, K in shapes:
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * 0.1

@@ -17,13 +17,12 @@ from timeautodiff_amd.DIFF import BiRNN_score, DiffusionTrainer  # noqa: E402
 def table(summ, reps, title):
     print(f"==== {title}: ms per iteration, sorted")
     rows = []
-    for key, (cnt, ms) in summ.items():
-        kind, fl, by = bench.kernel_cost(key)
+    for key, (cnt, ms, fl, by) in summ.items():
         avg = ms / cnt
         rows.append((ms / reps, cnt / reps, avg, fl / avg / 1e9 if avg > 0 else 0, by / avg / 1e6 if avg > 0 else 0, key))
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
-    for r in rows[:40]:
+    for r in rows[:60]:
         print(f"{r[0]:8.3f} ms  x{r[1]:5.1f}  avg {r[2]*1e3:8.1f} us  {r[3]:8.1f} TF/s  {r[4]:8.1f} GB/s  {r[5]}")
     print(f"total {tot:.3f} ms")
 

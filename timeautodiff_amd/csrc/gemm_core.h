@@ -65,7 +65,7 @@ struct GemmParams {
   int wide_epi;              // 16-byte epilogue possible (alignment of C, bias, residual, relu operand)
   int64_t k_per_split;
   int shiftT, shift;         // time-shifted rows of the B operand along k (see header)
-  int64_t tiles_n, ntiles;
+  int64_t tiles_n, ntiles, nsplits;
   // Gate map of the atomic epilogue and the row sums (map_H == 0: none).  Row n of the product is the
   // gate-interleaved index blk*4*map_H + 4*u + s; it is accumulated into row blk*map_G*map_H +
   // map_slot[s]*map_H + u of C (rowsum likewise), or dropped when map_slot[s] < 0.
@@ -580,17 +580,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it is wave-uniform
   const int wm = wave / WN, wn = wave % WN;
-  // XCD-aware tile assignment: workgroups with equal blockIdx % 8 share an XCD (L2); give each
-  // such group a contiguous run of tiles (bijective for any tile count).
-  int64_t tile;
+  // XCD-aware work assignment: workgroups with equal blockIdx % 8 share an XCD (L2).  The work items
+  // (reduction split z, tile), z-major, are dealt out so that each XCD owns a contiguous run (bijective
+  // for any count): neighbouring tiles share a row panel, and the tiles of one reduction split share
+  // the slabs of both operands, which then come out of that XCD's L2 after the first read.
+  int64_t tile, zsplit;
   {
-    const int64_t bid = blockIdx.x, nt = p.ntiles;
-    const int64_t xcd = bid % 8, local = bid / 8, q = nt / 8, r = nt % 8;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    const int64_t bid = blockIdx.x, nw = p.ntiles * p.nsplits;
+    const int64_t xcd = bid % 8, local = bid / 8, q = nw / 8, r = nw % 8;
+    const int64_t w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    zsplit = w / p.ntiles;
+    tile = w % p.ntiles;
   }
   const int64_t tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int64_t i0 = tm * BM, j0 = tn * BN;
-  const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
+  const int64_t kbeg = zsplit * p.k_per_split;
   const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
   const int nt = (int)((kend - kbeg + BK - 1) / BK);
   if (nt <= 0) return;
@@ -816,7 +820,8 @@ void launch_cfg(GemmParams& p, int splits, hipStream_t s) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   p.tiles_n = cdiv64(p.N, BN);
   p.ntiles = cdiv64(p.M, BM) * p.tiles_n;
-  dim3 grid((unsigned)p.ntiles, 1, (unsigned)splits);
+  p.nsplits = splits;
+  dim3 grid((unsigned)(p.ntiles * splits));
   p.wide_epi = wide_epilogue_ok(p);
   const bool vec = (AK >= KC16 || operand_vec_ok(AK, p.A, p.sa_row, p.sa_k, p.M, p.K)) &&
                    (BKD >= KC16 || operand_vec_ok(BKD, p.B, p.sb_row, p.sb_k, p.N, p.K));
@@ -841,7 +846,9 @@ inline TileDim tile_dim(Cfg c) {
 // Widest tile that still gives every CU a workgroup or two; split-k launches (min_wgs == 0) fill
 // the chip through the split count instead.
 inline Cfg pick_cfg(int prec, int64_t M, int64_t N, int64_t min_wgs) {
-  Cfg big = prec == TAD_BF16 ? (N > 256 ? CFG_W : CFG_S) : CFG_F;
+  // bf16: the square 256 x 256 tile measured fastest for all three products at the bench shapes
+  // (98 304 x 1600 x 128..400); the 128 x 512 tile (W) stays selectable for experiments
+  Cfg big = prec == TAD_BF16 ? CFG_S : CFG_F;
   static const char* force = getenv("TAD_GEMM_CFG");     // experiments: W, S, H or T for every bf16 launch
   if (force && prec == TAD_BF16) return force[0] == 'W' ? CFG_W : force[0] == 'S' ? CFG_S : force[0] == 'H' ? CFG_H : CFG_T;
   const TileDim d = tile_dim(big);

@@ -325,66 +325,103 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[jj][r] = 0.f; dcs[jj][r] = 0.f; }
 
+  // Operands of one step for the owned (row, unit) elements: dout, the gate stash, and the states the cell
+  // needs (LSTM: c_t and c_{t-1}; GRU: h_{t-1}).  With one chunk per wave they are fetched one step ahead,
+  // right before the recurrent product of the step in progress, so their HBM latency hides under it;
+  // c_t is then carried over from the previous step's c_{t-1}.  The GRU has the registers for that; the
+  // LSTM (one more state and gate per element) would spill, so it fetches at the start of its step.
+  // (wave-uniform row bases + one 32-bit per-lane offset per buffer, as in the forward)
+  constexpr bool PREFETCH = (JPW == 1) && CELL == TAD_CELL_GRU;
+  float q_dout[JPW][16], q_cur[JPW][16], q_prev[JPW][16];
+  raw_t q_g[JPW][16];
+  auto fetch = [&](int stp, int jj, bool carry) {
+    const int n_ = T - 1 - stp;
+    const int tt_ = d.reverse ? T - 1 - n_ : n_;
+    const int tp_ = (n_ > 0) ? (d.reverse ? tt_ + 1 : tt_ - 1) : -1;
+    const int u = 32 * (wave + jj * nw) + col;
+    const bool uok = u < H;
+    const int rowT = 4 * half * T;
+    const uint32_t doff = (uint32_t)((rowT + tt_) * (int)d.ld_dout + u);
+    const uint32_t soff = (uint32_t)(((rowT + tt_) * (int)d.ld_gates + 4 * u) * SL::ESZ);
+    const uint32_t coff = (uint32_t)((rowT + tt_) * (int)d.ld_c + u);
+    const uint32_t cpoff = (uint32_t)((rowT + (tp_ >= 0 ? tp_ : 0)) * (int)d.ld_c + u);
+    const uint32_t ooff = (uint32_t)((rowT + (tp_ >= 0 ? tp_ : 0)) * (int)d.ld_out + u);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cr = (r & 3) + 8 * (r >> 2);
+      const bool ok = uok && (cr + 4 * half) < a.rpw && (b0 + cr + 4 * half) < a.B;
+      const int64_t rb = (b0 + cr) * (int64_t)T;
+      q_dout[jj][r] = ok ? (d.dout + rb * d.ld_dout)[doff] : 0.f;
+      q_g[jj][r] = ok ? *reinterpret_cast<const raw_t*>(reinterpret_cast<const unsigned char*>(d.gates) + rb * d.ld_gates * SL::ESZ + soff)
+                      : SL::zero();
+      if constexpr (CELL == TAD_CELL_LSTM) {
+        const float* cp = d.cstate + rb * d.ld_c;
+        q_cur[jj][r] = carry ? q_prev[jj][r] : (ok ? cp[coff] : 0.f);
+        q_prev[jj][r] = (ok && tp_ >= 0) ? cp[cpoff] : 0.f;
+      } else {
+        q_prev[jj][r] = (ok && tp_ >= 0) ? (d.out + rb * d.ld_out)[ooff] : 0.f;
+      }
+    }
+  };
+  if constexpr (PREFETCH) {
+    if (wave < a.NJ) fetch(0, 0, false);
+  }
+
   for (int step = 0; step < T; ++step) {
     const int n = T - 1 - step;                       // forward step being undone
     const int tt = d.reverse ? T - 1 - n : n;
-    const int tprev = (n > 0) ? (d.reverse ? tt + 1 : tt - 1) : -1;
     // ---- phase 1: gate gradients for the owned (row, unit) elements
-    // (wave-uniform row bases + one 32-bit per-lane offset per buffer, as in the forward)
 #pragma unroll
     for (int jj = 0; jj < JPW; ++jj) {
       const int j = wave + jj * nw;
       if (j < a.NJ) {
         const int u = 32 * j + col;
         const bool uok = u < H;
-        const int rowT = 4 * half * T;
-        const uint32_t doff = (uint32_t)((rowT + tt) * (int)d.ld_dout + u);
-        const uint32_t soff = (uint32_t)(((rowT + tt) * (int)d.ld_gates + 4 * u) * SL::ESZ);
-        const uint32_t coff = (uint32_t)((rowT + tt) * (int)d.ld_c + u);
-        const uint32_t cpoff = (uint32_t)((rowT + (tprev >= 0 ? tprev : 0)) * (int)d.ld_c + u);
-        const uint32_t ooff = (uint32_t)((rowT + (tprev >= 0 ? tprev : 0)) * (int)d.ld_out + u);
-        const uint32_t goff = (uint32_t)(((rowT + tt) * (int)d.ld_dgates + 4 * u) * SL::ESZ);
+        if constexpr (!PREFETCH) fetch(step, jj, false);
+        const uint32_t goff = (uint32_t)(((4 * half * T + tt) * (int)d.ld_dgates + 4 * u) * SL::ESZ);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cr = (r & 3) + 8 * (r >> 2);
           const int row = cr + 4 * half;
           const bool ok = uok && row < a.rpw && (b0 + row) < a.B;
           float da[G];
-          float nacc = 0.f;
-#pragma unroll
-          for (int g = 0; g < G; ++g) da[g] = 0.f;
+          float nacc;
+          // rows / units outside the batch carry zeros through the same arithmetic
+          const float dh = q_dout[jj][r] + acc[jj][r];
+          const f32x4 gv = SL::unpack(q_g[jj][r]);
+          raw_t dgv;
+          if constexpr (CELL == TAD_CELL_LSTM) {
+            const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+            const float c = q_cur[jj][r], cprev = q_prev[jj][r];
+            const float tc = fast_tanh(c);
+            const float dog = dh * tc;
+            const float dc = dh * og * (1.f - tc * tc) + dcs[jj][r];
+            dcs[jj][r] = dc * fg;
+            da[0] = dc * gg * ig * (1.f - ig);
+            da[1] = dc * cprev * fg * (1.f - fg);
+            da[2] = dc * ig * (1.f - gg * gg);
+            da[3] = dog * og * (1.f - og);
+            dgv = SL::pack(da[0], da[1], da[2], da[3]);
+            nacc = 0.f;
+          } else {
+            const float rg = gv[0], zg = gv[1], ng = gv[2], hpn = gv[3];
+            const float hprev = q_prev[jj][r];
+            const float dn = dh * (1.f - zg);
+            const float dz = dh * (hprev - ng);
+            const float dan = dn * (1.f - ng * ng);
+            const float dar = dan * hpn * rg * (1.f - rg);
+            const float daz = dz * zg * (1.f - zg);
+            da[0] = dar; da[1] = daz; da[2] = dan * rg;
+            dgv = SL::pack(dar, daz, dan, da[2]);
+            nacc = dh * zg;
+          }
           if (ok) {
-            const int64_t rb = (b0 + cr) * (int64_t)T;
-            const float dh = (d.dout + rb * d.ld_dout)[doff] + acc[jj][r];
-            const f32x4 gv = SL::unpack(*reinterpret_cast<const raw_t*>(
-                reinterpret_cast<const unsigned char*>(d.gates) + rb * d.ld_gates * SL::ESZ + soff));
-            unsigned char* dgp = reinterpret_cast<unsigned char*>(d.dgates) + rb * d.ld_dgates * SL::ESZ;
-            if constexpr (CELL == TAD_CELL_LSTM) {
-              const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
-              const float* cp = d.cstate + rb * d.ld_c;
-              const float c = cp[coff];
-              const float cprev = (tprev >= 0) ? cp[cpoff] : 0.f;
-              const float tc = fast_tanh(c);
-              const float dog = dh * tc;
-              const float dc = dh * og * (1.f - tc * tc) + dcs[jj][r];
-              dcs[jj][r] = dc * fg;
-              da[0] = dc * gg * ig * (1.f - ig);
-              da[1] = dc * cprev * fg * (1.f - fg);
-              da[2] = dc * ig * (1.f - gg * gg);
-              da[3] = dog * og * (1.f - og);
-              *reinterpret_cast<raw_t*>(dgp + goff) = SL::pack(da[0], da[1], da[2], da[3]);
-            } else {
-              const float rg = gv[0], zg = gv[1], ng = gv[2], hpn = gv[3];
-              const float hprev = (tprev >= 0) ? (d.out + rb * d.ld_out)[ooff] : 0.f;
-              const float dn = dh * (1.f - zg);
-              const float dz = dh * (hprev - ng);
-              const float dan = dn * (1.f - ng * ng);
-              const float dar = dan * hpn * rg * (1.f - rg);
-              const float daz = dz * zg * (1.f - zg);
-              da[0] = dar; da[1] = daz; da[2] = dan * rg;
-              *reinterpret_cast<raw_t*>(dgp + goff) = SL::pack(dar, daz, dan, da[2]);
-              nacc = dh * zg;
-            }
+            unsigned char* dgp = reinterpret_cast<unsigned char*>(d.dgates) + (b0 + cr) * (int64_t)T * d.ld_dgates * SL::ESZ;
+            *reinterpret_cast<raw_t*>(dgp + goff) = dgv;
+          } else {
+            nacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) da[g] = 0.f;
           }
           acc[jj][r] = nacc;
           if constexpr (!PHASED) {
@@ -393,6 +430,9 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
           }
         }
       }
+    }
+    if constexpr (PREFETCH) {
+      if (wave < a.NJ && step + 1 < T) fetch(step + 1, 0, true);
     }
     // ---- phase 2: dh_rec = dgates * W_hh (K = G * width), A operand from LDS
     if constexpr (!PHASED) {
@@ -615,7 +655,7 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, 
               "tad_rnn_bwd: LSTM needs cstate, GRU needs out (dir %d)", i);
     TAD_CHECK(di.ld_dout >= H && gl_ok(di.gates, di.ld_gates, H) && gl_ok(di.dgates, di.ld_dgates, H),
               "tad_rnn_bwd: bad alignment / leading dimension in dir %d", i);
-    TAD_CHECK((5 * T + 1) * (di.ld_dout + di.ld_out + di.ld_gates + di.ld_c + di.ld_dgates) * 4 < (int64_t)1 << 31,
+    TAD_CHECK((32 * T + 1) * (di.ld_dout + di.ld_out + di.ld_gates + di.ld_c + di.ld_dgates) * 4 < (int64_t)1 << 31,
               "tad_rnn_bwd: T * ld too large for 32-bit lane offsets");
   }
   const int ks = ks_of(bf);

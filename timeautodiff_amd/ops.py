@@ -63,20 +63,21 @@ class LaunchTrace:
         _TRACE = self._prev
 
     def summary(self):
+        """{(entry point, integer args): [calls, total_ms, algorithmic FLOPs per call, algorithmic HBM bytes per call]}."""
         torch.cuda.synchronize()
         out = {}
-        for key, _, e0, e1 in self.records:
-            ent = out.setdefault(key, [0, 0.0])
+        for key, _, e0, e1, cost in self.records:
+            ent = out.setdefault(key, [0, 0.0, cost[0], cost[1]])
             ent[0] += 1
             ent[1] += e0.elapsed_time(e1)
         return out
 
     def summary_by_kernel(self):
-        """{device kernel name (entry point name if the call names no kernel): {key: [calls, total_ms]}}."""
+        """{device kernel name (entry point name if the call names no kernel): {key: [calls, total_ms, flops, bytes]}}."""
         torch.cuda.synchronize()
         out = {}
-        for key, kern, e0, e1 in self.records:
-            ent = out.setdefault(kern or key[0], {}).setdefault(key, [0, 0.0])
+        for key, kern, e0, e1, cost in self.records:
+            ent = out.setdefault(kern or key[0], {}).setdefault(key, [0, 0.0, cost[0], cost[1]])
             ent[0] += 1
             ent[1] += e0.elapsed_time(e1)
         return out
@@ -85,7 +86,9 @@ class LaunchTrace:
 _TRACE = None
 
 
-def _call(name, *args):
+def _call(name, *args, cost=(0.0, 0.0)):
+    """Calls a C-ABI entry point.  ``cost`` = (algorithmic FLOPs, algorithmic HBM bytes: every operand and result
+    once at its storage width) of the call, recorded by an installed LaunchTrace."""
     lib = _lib.load()
     if _TRACE is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -94,7 +97,7 @@ def _call(name, *args):
         rc = getattr(lib, name)(*args)
         e1.record()
         key = (name,) + tuple(a for a in args[:6] if isinstance(a, int) and abs(a) < (1 << 40))
-        _TRACE.records.append((key, lib.tad_last_kernel().decode(), e0, e1))
+        _TRACE.records.append((key, lib.tad_last_kernel().decode(), e0, e1, cost))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:
@@ -115,7 +118,8 @@ def linear_fwd(prec, x, w, bias, y, act=ACT_NONE, accumulate=False, bias2=None, 
     elif residual is not None:
         rp, Mr, Nr, ldr = as2d(residual)
         assert Mr == M and Nr == N
-    _call("tad_linear_fwd", prec, M, N, K, xp, ldx, wp, ldw, _ptr(bias), _ptr(bias2), rp, ldr, yp, ldy, act, _stream())
+    _call("tad_linear_fwd", prec, M, N, K, xp, ldx, wp, ldw, _ptr(bias), _ptr(bias2), rp, ldr, yp, ldy, act, _stream(),
+          cost=(2.0 * M * N * K, 4.0 * (M * K + N * K + M * N + (M * N if rp else 0))))
 
 
 def linear_bwd_data(prec, dy, w, dx, relu_of=None, accumulate=False):
@@ -127,7 +131,8 @@ def linear_bwd_data(prec, dy, w, dx, relu_of=None, accumulate=False):
     if relu_of is not None:
         rp, Mr, Kr, ldr = as2d(relu_of)
         assert Mr == M and Kr == K
-    _call("tad_linear_bwd_data", prec, M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream())
+    _call("tad_linear_bwd_data", prec, M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream(),
+          cost=(2.0 * M * N * K, 4.0 * (M * N + N * K + M * K * (1 + bool(rp) + bool(accumulate)))))
 
 
 def _gate_map(gate_map):
@@ -154,13 +159,14 @@ def linear_bwd_weight(prec, dy, x, dw, db=None, db2=None, T=0, tshift=0, gate_ma
     assert M == Mx and n_out == Nw and K == Kw, (dy.shape, x.shape, dw.shape, gate_map)
     for b in (db, db2):
         assert b is None or (b.is_contiguous() and b.numel() == n_out), (n_out, None if b is None else b.shape)
+    cost = (2.0 * M * N * K, dy.element_size() * M * N + 4.0 * M * K + 4.0 * n_out * K)
     if b16:
         assert prec == BF16
         _call("tad_linear_bwd_weight_b16", M, N, K, dyp, ldy, xp, ldx, dwp, ldw, _ptr(db), _ptr(db2), T, tshift,
-              _gate_map(gate_map), _stream())
+              _gate_map(gate_map), _stream(), cost=cost)
     else:
         _call("tad_linear_bwd_weight", prec, M, N, K, dyp, ldy, xp, ldx, dwp, ldw, _ptr(db), _ptr(db2), T, tshift,
-              _gate_map(gate_map), _stream())
+              _gate_map(gate_map), _stream(), cost=cost)
 
 
 def linear_fwd_b16(x, w16, bias, y, act=ACT_NONE):
@@ -170,7 +176,7 @@ def linear_fwd_b16(x, w16, bias, y, act=ACT_NONE):
     yp, My, Ny, ldy = as2d(y, y.dtype)
     assert K == Kw and M == My and N == Ny, (x.shape, w16.shape, y.shape)
     _call("tad_linear_fwd_b16", M, N, K, xp, ldx, wp, ldw, _ptr(bias), yp, BF16 if y.dtype == torch.bfloat16 else F32, ldy,
-          act, _stream())
+          act, _stream(), cost=(2.0 * M * N * K, 4.0 * M * K + 2.0 * N * K + y.element_size() * M * N))
 
 
 def linear_bwd_data_b16(dy16, w16, dx, relu_of=None, accumulate=False):
@@ -183,7 +189,8 @@ def linear_bwd_data_b16(dy16, w16, dx, relu_of=None, accumulate=False):
     if relu_of is not None:
         rp, Mr, Kr, ldr = as2d(relu_of)
         assert Mr == M and Kr == K
-    _call("tad_linear_bwd_data_b16", M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream())
+    _call("tad_linear_bwd_data_b16", M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream(),
+          cost=(2.0 * M * N * K, 2.0 * (M * N + N * K) + 4.0 * M * K * (1 + bool(rp) + bool(accumulate))))
 
 
 def colsum(dy, out_sum=None, out_sum2=None, row_scale=None, row_scale_stride=1, scale_mul=1.0, out_wsum=None):
@@ -237,7 +244,11 @@ def rnn_fwd(cell, prec, B, T, H, dirs):
                 cp, _, _, ldc = as2d(d["cstate"])
         arr[k] = RnnDir(xp, ldxp, d["w_packed"].data_ptr(), _ptr(d.get("b_hh")), op, ldo, gp, ldg, cp, ldc,
                         int(d["reverse"]), 0)
-    _call("tad_rnn_fwd", cell, prec, store, B, T, H, len(dirs), arr, _stream())
+    G, nd, esz = (4 if cell == CELL_LSTM else 3), len(dirs), dirs[0]["xproj"].element_size()
+    train = dirs[0].get("gates") is not None
+    per_elem = 4 * esz + 4 + ((4 * esz + (4 if cell == CELL_LSTM else 0)) if train else 0)     # xproj in, h out, stash out
+    _call("tad_rnn_fwd", cell, prec, store, B, T, H, nd, arr, _stream(),
+          cost=(2.0 * B * T * nd * G * H * H, float(B * T * nd * H * per_elem)))
 
 
 def rnn_bwd(cell, prec, B, T, H, dirs):
@@ -256,7 +267,10 @@ def rnn_bwd(cell, prec, B, T, H, dirs):
             op, _, _, ldo = as2d(d["out"])
         gp, _, _, ldg = as2d(d["dgates"], dt)
         arr[k] = RnnBwdDir(dp, ldd, sp, lds, cp, ldc, op, ldo, d["w_packed_t"].data_ptr(), gp, ldg, int(d["reverse"]), 0)
-    _call("tad_rnn_bwd", cell, prec, store, B, T, H, len(dirs), arr, _stream())
+    G, nd, esz = (4 if cell == CELL_LSTM else 3), len(dirs), dirs[0]["gates"].element_size()
+    per_elem = 4 + 4 * esz + 4 + 4 * esz                                    # dout, stash, c or h_prev, dgates out
+    _call("tad_rnn_bwd", cell, prec, store, B, T, H, nd, arr, _stream(),
+          cost=(2.0 * B * T * nd * G * H * H, float(B * T * nd * H * per_elem)))
 
 
 # ------------------------------------------------------------------ elementwise family
