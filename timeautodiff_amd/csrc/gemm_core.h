@@ -810,8 +810,6 @@ inline bool wide_epilogue_ok(const GemmParams& p) {
          (!p.relu_of || (p.ld_relu % 4 == 0 && aligned16(p.relu_of)));
 }
 
-constexpr const char* kind_name(int k) { return k == KC32 ? "KC32" : k == RC32 ? "RC32" : k == KC16 ? "KC16" : "RC16"; }
-
 // Launches one tile configuration.  VEC selects the 16-byte loaders of the fp32 operands; 16-bit operands
 // have no scalar-load form: the caller has checked operand_vec_ok for them (entry points reject misaligned
 // bf16 operands).
@@ -827,8 +825,9 @@ void launch_cfg(GemmParams& p, int splits, hipStream_t s) {
                    (BKD >= KC16 || operand_vec_ok(BKD, p.B, p.sb_row, p.sb_k, p.N, p.K));
   if (vec) hipLaunchKernelGGL((gemm_kernel<BF16, AK, BKD, true, WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, s, p);
   else hipLaunchKernelGGL((gemm_kernel<BF16, AK, BKD, false, WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, s, p);
-  tad_note_kernel("gemm_kernel<%s, %s, %s, %s, %d, %d, %d, %d>", BF16 ? "true" : "false", kind_name(AK), kind_name(BKD),
-                  vec ? "true" : "false", WM, WN, TM, TN);
+  // the name as a profiler prints it (operand kinds as their enum values: 0 KC32, 1 RC32, 2 KC16, 3 RC16)
+  tad_note_kernel("gemm_kernel<%s, %d, %d, %s, %d, %d, %d, %d>", BF16 ? "true" : "false", AK, BKD, vec ? "true" : "false", WM, WN, TM,
+                  TN);
 }
 
 enum Cfg { CFG_W, CFG_S, CFG_F, CFG_T, CFG_H };
