@@ -253,6 +253,14 @@ int tad_vae_heads_loss(int64_t rows, int nb, int nc, int nn, const int32_t* card
                        const float* mask, const float* target, int64_t ldf, float scale_bce, float scale_ce,
                        float scale_mse, float* dheads, float* loss_parts, tad_stream_t stream);
 
+/* convert_to_tensor (process_edited.py:252-301), the step every driver runs on the decoder's
+ * outputs after sampling: `heads` [rows, NH] holds the reference-visible head outputs in
+ * the column order bins | cat_0 | ... | nums (as tad_vae_heads_loss leaves them);
+ * out[r, :] = [ sigmoid(bin) > 0.5 ? 1 : 0 | first argmax of softmax(cat_j) | nums ],
+ * rows of F = nb + nc + nn floats, row stride ldo. */
+int tad_heads_to_tensor(int64_t rows, int nb, int nc, int nn, const int32_t* cards, const float* heads, int64_t ldh,
+                        float* out, int64_t ldo, tad_stream_t stream);
+
 /* inp = a + b and target = (a + b) * mask (VAE.py:331-336), elementwise over n. */
 int tad_vae_prepare(int64_t n, const float* resp, const float* cond, const float* mask, float* inp, float* target,
                     tad_stream_t stream);

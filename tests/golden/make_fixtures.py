@@ -259,6 +259,48 @@ def vae_loop_case(VAE, name, schema, H, T, L, N, Nv, B, steps, seed, fn_name):
     print(name, "train", hist["train"][:2], hist["train"][-1], "val", hist["val"][-1])
 
 
+def convert_case(ref, name, schema, B, T, seed):
+    """process_edited.convert_to_tensor (process_edited.py:252-301) on seeded decoder outputs that include exact
+    ties, zeros and near-threshold logits.  The function reads the module global ``device`` (hard-coded 'cuda',
+    process_edited.py:250) at call time; it is pointed at 'cpu' for this run, the source is untouched."""
+    import torch
+    sys.path.insert(0, ref)
+    import process_edited as pce
+    pce.device = "cpu"
+    rng = np.random.default_rng(seed)
+    nb, nc, nn_, cards = schema["n_bins"], schema["n_cats"], schema["n_nums"], list(schema["cards"])
+    gen, save = {}, {}
+    if nb:
+        x = (rng.standard_normal((B, T, nb)) * 2).astype(np.float32)
+        x.flat[::7] = 0.0
+        x.flat[3::11] = np.float32(1e-3) * rng.standard_normal(x.flat[3::11].shape).astype(np.float32)
+        x.flat[5::13] -= 100.0                                    # masked-out entries carry the -100 offset
+        gen["bins"] = torch.from_numpy(x)
+        save["in/bins"] = x
+    if cards:
+        gen["cats"] = []
+        for j, c in enumerate(cards):
+            x = rng.standard_normal((B, T, c)).astype(np.float32)
+            if c > 1:
+                x[::3, :, c - 1] = x[::3].max(-1)                # exact ties between the last class and the maximum
+                x[1::4, ::2, 0] += 100.0                          # masked-out entries: +100 on class 0
+            gen["cats"].append(torch.from_numpy(x))
+            save[f"in/cats{j}"] = x
+    if nn_:
+        x = rng.random((B, T, nn_), dtype=np.float32)
+        gen["nums"] = torch.from_numpy(x)
+        save["in/nums"] = x
+
+    class P:
+        def datatype_info(self):
+            return dict(schema)
+    out = pce.convert_to_tensor(P(), gen, 1, B, T)
+    out2 = pce.convert_to_tensor(P(), gen, 1, None, None)
+    assert torch.equal(out, out2)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), out=out.numpy().astype(np.float32),
+                        meta=fu.pack_meta(dict(schema=schema, B=B, T=T, seed=seed)), **save)
+
+
 def schedule_case(DIFF):
     np.savez_compressed(os.path.join(HERE, "schedule.npz"), betas=DIFF.betas.numpy(), alphas=DIFF.alphas.numpy())
 
@@ -266,11 +308,17 @@ def schedule_case(DIFF):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="", help="'convert': write only the convert_to_tensor fixtures")
     a = ap.parse_args()
     DIFF, VAE = import_reference(a.ref)
     import torch
     torch.set_num_threads(4)
     S = fu.SCHEMAS
+    convert_case(a.ref, "convert_mixed", S["mixed"], B=6, T=8, seed=61)
+    convert_case(a.ref, "convert_metro", S["metro"], B=5, T=6, seed=62)
+    convert_case(a.ref, "convert_numeric", S["numeric"], B=4, T=5, seed=63)
+    if a.only == "convert":
+        return
     schedule_case(DIFF)
     denoiser_case(DIFF, "den_numeric_small", S["numeric"], H=24, E=16, T=8, B=5, K=6, seed=11)
     denoiser_case(DIFF, "den_mixed_small", S["mixed"], H=24, E=16, T=8, B=5, K=6, seed=12)

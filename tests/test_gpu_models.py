@@ -246,6 +246,24 @@ def test_vae_module_surface(dev):
     assert fu.rel_err(emb.cpu().numpy(), z["z"]) < TOL and fu.rel_err(out["nums"].cpu().numpy(), z["out/nums"]) < TOL
     dec = ae.decoder(torch.from_numpy(z["z"]), torch.from_numpy(data["mask"]), torch.from_numpy(data["cond"]))
     assert fu.rel_err(dec["bins"].cpu().numpy(), z["out/bins"]) < TOL
+    # decoder -> convert_to_tensor, as every driver does after sampling (Run_Imputation.ipynb:171-172): the fused
+    # path equals the two-step path, and both equal the oracle's conversion of the reference's decoder outputs
+    from oracle import convert as oconv
+    from timeautodiff_amd import process_edited as pce
+
+    class P:
+        def datatype_info(self):
+            return dict(meta["schema"])
+    args = (torch.from_numpy(z["z"]), torch.from_numpy(data["mask"]), torch.from_numpy(data["cond"]))
+    fused = ae.decode_to_tensor(*args)
+    two_step = pce.convert_to_tensor(P(), ae.decoder(*args), 1, meta["B"], meta["T"])
+    assert torch.equal(fused, two_step)
+    ref_gen = dict(bins=z["out/bins"], cats=[z[f"out/cats{j}"] for j in range(sch.n_cats)], nums=z["out/nums"])
+    ref_tab = oconv.convert_to_tensor(ref_gen, sch.n_bins, sch.n_cats, sch.n_nums, sch.cards)
+    got = fused.cpu().numpy()
+    nd = sch.n_bins + sch.n_cats
+    assert np.array_equal(got[..., :nd], ref_tab[..., :nd])                   # codes: exact
+    assert fu.rel_err(got[..., nd:], ref_tab[..., nd:]) < TOL                 # numericals: decoder tolerance
     # auto_loss on decoded outputs reproduces the reference's (disc, num)
     from timeautodiff_amd import VAE
     target = (inp * torch.from_numpy(data["mask"])).to(dev)

@@ -200,3 +200,22 @@ def test_vae_loss_curve(name, select):
     eps = torch.randn(N, T, L).numpy()
     zl, _, _, _ = vae.encoder_fwd(best, tr["response"] + tr["cond"], eps, sch)
     assert fu.rel_err(zl, z["latent"]) < 1e-3
+
+
+# ---------------------------------------------------------------------------- convert_to_tensor
+@pytest.mark.parametrize("name", ["convert_mixed", "convert_metro", "convert_numeric"])
+def test_convert_to_tensor_matches_reference(name):
+    """oracle.convert vs process_edited.convert_to_tensor run by the reference: exact (codes, thresholds, copies)."""
+    from oracle import convert as oconv
+    z, meta = fu.load(name)
+    sch = meta["schema"]
+    gen = {}
+    if sch["n_bins"]:
+        gen["bins"] = z["in/bins"]
+    if sch["cards"]:
+        gen["cats"] = [z[f"in/cats{j}"] for j in range(len(sch["cards"]))]
+    if sch["n_nums"]:
+        gen["nums"] = z["in/nums"]
+    out = oconv.convert_to_tensor(gen, sch["n_bins"], sch["n_cats"], sch["n_nums"], sch["cards"])
+    assert out.dtype == np.float32 and out.shape == z["out"].shape
+    assert np.array_equal(out, z["out"])

@@ -95,6 +95,19 @@ class DeapStack(nn.Module):
         heads = eng.decoder(z, self._dev_f32(mask, eng), self._dev_f32(cond, eng) if cond is not None else None)
         return eng.split_heads(heads, B, T)
 
+    def decode_to_tensor(self, latent_feature, mask=None, cond=None):
+        """decoder (VAE.py:193-215) followed by convert_to_tensor (process_edited.py:252-301) -- what every
+        driver does with sampled latents -- without materialising the dict: [B,T,F] float32 of thresholded
+        bins, argmax codes and numericals."""
+        eng = self.engine(latent_feature.device if latent_feature.is_cuda else None)
+        eng.fp.version += 1
+        z = self._dev_f32(latent_feature, eng)
+        B, T, _ = z.shape
+        heads = eng.decoder(z, self._dev_f32(mask, eng), self._dev_f32(cond, eng) if cond is not None else None)
+        out = torch.empty(B, T, eng.F, dtype=torch.float32, device=eng.device)
+        ops.heads_to_tensor(heads, eng.nb, eng.nc, eng.nn, eng.cards, out.view(B * T, eng.F))
+        return out
+
     def forward(self, x, mask, cond=None, *, eps=None):
         emb, mu_z, logvar_z = self.encoder(x, eps=eps)
         outputs = self.decoder(emb, mask, cond)

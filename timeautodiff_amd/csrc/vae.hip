@@ -119,6 +119,36 @@ __global__ void prepare_kernel(int64_t n, const float* __restrict__ a, const flo
   }
 }
 
+// Decoder outputs -> data table row (convert_to_tensor): one thread per row.
+//   bins: 1 where sigmoid(logit) > 0.5, evaluated in fp32 as 1 / (1 + exp(-x)) like torch.sigmoid;
+//   cats: index of the first maximum of the fp32 softmax exp(x - max) / sum (torch.argmax of F.softmax);
+//   nums: copied.
+__global__ void heads_to_tensor_kernel(int64_t rows, int nb, int nc, int nn, HeadMeta hm, const float* __restrict__ heads,
+                                       int64_t ldh, float* __restrict__ out, int64_t ldo) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* h = heads + r * ldh;
+  float* o = out + r * ldo;
+  int col = 0;
+  for (int j = 0; j < nb; ++j, ++col) o[j] = sigmoid_acc(h[col]) > 0.5f ? 1.f : 0.f;
+  for (int j = 0; j < nc; ++j) {
+    const int card = hm.card[j];
+    float mx = h[col];
+    for (int q = 1; q < card; ++q) mx = fmaxf(mx, h[col + q]);
+    float se = 0.f;
+    for (int q = 0; q < card; ++q) se += expf(h[col + q] - mx);
+    int best = 0;
+    float pb = expf(h[col] - mx) / se;
+    for (int q = 1; q < card; ++q) {
+      const float pq = expf(h[col + q] - mx) / se;
+      if (pq > pb) { pb = pq; best = q; }
+    }
+    o[nb + j] = (float)best;
+    col += card;
+  }
+  for (int j = 0; j < nn; ++j, ++col) o[nb + nc + j] = h[col];
+}
+
 inline unsigned vgrid(int64_t n) {
   int64_t g = cdiv64(n, VB);
   if (g > 2048) g = 2048;
@@ -170,6 +200,25 @@ extern "C" int tad_vae_prepare(int64_t n, const float* resp, const float* cond, 
   TAD_CHECK(n >= 0 && resp && (!target || mask), "tad_vae_prepare: bad arguments");
   if (n == 0) return TAD_OK;
   hipLaunchKernelGGL(prepare_kernel, dim3(vgrid(n)), dim3(VB), 0, (hipStream_t)stream, n, resp, cond, mask, inp, target);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_heads_to_tensor(int64_t rows, int nb, int nc, int nn, const int32_t* cards, const float* heads, int64_t ldh,
+                                   float* out, int64_t ldo, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && nb >= 0 && nc >= 0 && nn >= 0 && nc <= MAX_CATS && heads && out, "tad_heads_to_tensor: bad arguments");
+  TAD_CHECK(nc == 0 || cards, "tad_heads_to_tensor: cards missing");
+  HeadMeta hm{};
+  int64_t nh = nb + nn;
+  for (int j = 0; j < nc; ++j) {
+    TAD_CHECK(cards[j] > 0, "tad_heads_to_tensor: bad cardinality");
+    hm.card[j] = cards[j];
+    nh += cards[j];
+  }
+  TAD_CHECK(ldh >= nh && ldo >= nb + nc + nn, "tad_heads_to_tensor: bad leading dimension");
+  if (rows == 0) return TAD_OK;
+  hipLaunchKernelGGL(heads_to_tensor_kernel, dim3((unsigned)cdiv64(rows, VB)), dim3(VB), 0, (hipStream_t)stream, rows, nb, nc, nn, hm,
+                     heads, ldh, out, ldo);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

@@ -392,3 +392,12 @@ def vae_heads_loss(heads, mask, target, nb, nc, nn, cards, s_bce, s_ce, s_mse, d
 
 def vae_prepare(resp, cond, mask, inp, target):
     _call("tad_vae_prepare", resp.numel(), resp.data_ptr(), _ptr(cond), _ptr(mask), _ptr(inp), _ptr(target), _stream())
+
+
+def heads_to_tensor(heads, nb, nc, nn, cards, out):
+    """Decoder head outputs [rows, NH] (bins | cats | nums) -> table rows [rows, F] (thresholded bins, argmax codes, nums)."""
+    hp, rows, NH, ldh = as2d(heads)
+    op, rows2, F, ldo = as2d(out)
+    assert rows == rows2 and F == nb + nc + nn and NH == nb + sum(cards[:nc]) + nn, (heads.shape, out.shape)
+    _call("tad_heads_to_tensor", rows, nb, nc, nn, _i32(list(cards)) if nc else None, hp, ldh, op, ldo, _stream(),
+          cost=(0.0, 4.0 * rows * (NH + F)))
