@@ -13,6 +13,7 @@
 // Accumulator layout (v_mfma_f32_32x32x*): column = lane & 31 = unit within the chunk,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = batch row within the tile.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
   const int64_t b0 = (int64_t)blockIdx.x * a.rpw;   // rows >= rpw of the 32-row MFMA tile stay empty
   const size_t buf_bytes = (size_t)32 * a.lds_ld * ESZ;
   const int H = a.H, T = a.T;
+  const int rlive = a.rpw >> 1;                     // accumulator registers that hold real rows (rpw is 8, 16 or 32)
   const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed);
 
   for (size_t i = threadIdx.x; i < 2 * buf_bytes / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
@@ -259,6 +261,11 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
         const uint32_t coff = (uint32_t)((4 * half * T + tt) * (int)d.ld_c + u);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          // accumulator register r holds tile rows cr and cr + 4: with fewer than 32 real rows per workgroup
+          // (small batches) registers r >= rpw / 2 hold no row of the batch and skip the gate math -- the
+          // step is bound by it (10 quarter-rate exp / rcp per element), not by the matrix product.
+          // Their rows of the LDS operand stay the zeros both buffers start with.
+          if (r >= rlive) continue;
           const int cr = (r & 3) + 8 * (r >> 2);
           const int row = cr + 4 * half;
           const bool ok = uok && row < a.rpw && (b0 + row) < a.B;
@@ -317,6 +324,14 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
   const int H = a.H, T = a.T;
   const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed_t);
   const int half = lane >> 5;
+  // accumulator registers that hold real rows (see the forward); the rest skip phase 1, their rows of the
+  // LDS tile stay the zeros it is cleared to here, so their accumulators stay zero
+  const int rlive = a.rpw >> 1;
+  if (!PHASED && a.rpw < 32) {
+    const size_t words = (size_t)32 * a.lds_ld * (BF16 ? 2 : 4) / 4;
+    for (size_t i = threadIdx.x; i < words; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+    __syncthreads();
+  }
 
   f32x16 acc[JPW];
   float dcs[JPW][16];
@@ -381,6 +396,7 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
         const uint32_t goff = (uint32_t)(((4 * half * T + tt) * (int)d.ld_dgates + 4 * u) * SL::ESZ);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          if (r >= rlive) continue;
           const int cr = (r & 3) + 8 * (r >> 2);
           const int row = cr + 4 * half;
           const bool ok = uok && row < a.rpw && (b0 + row) < a.B;
@@ -512,6 +528,8 @@ struct Geom {
 // HBM traffic (xproj in, h / stash out) over more CUs -- the step time is bound by the
 // per-CU memory path, not by the matrix cores, in that regime.
 int rows_per_wg(int64_t B, int ndir) {
+  static const char* force = getenv("TAD_RNN_RPW");      // experiments: 8, 16 or 32
+  if (force) return atoi(force);
   int rpw = 32;
   while (rpw > 8 && cdiv64(B, rpw) * ndir < 256) rpw >>= 1;
   return rpw;
