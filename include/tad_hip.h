@@ -224,6 +224,13 @@ int tad_layernorm_bwd(int64_t rows, int D, const float* dy, int64_t lddy, const 
 int tad_gather_rows(int64_t rows, int64_t row_len, const float* src, const int64_t* idx, float* out,
                     tad_stream_t stream);
 
+/* Minibatch of sliding windows straight from the [rows, F] table they are cut from
+ * (dataprovider_pypots.py:75-87 `sliding_window` followed by the trainers' index gather, DIFF.py:320,
+ * VAE.py:340-348): out[b, t, :] = table[idx[b] * stride + t, :], b < B, t < T.  The caller guarantees
+ * idx[b] * stride + T <= rows of the table.  Window i of the reference's stacked tensor is idx = i. */
+int tad_gather_windows(int64_t B, int64_t T, int64_t F, int64_t stride, const float* table, int64_t ld,
+                       const int64_t* idx, float* out, tad_stream_t stream);
+
 /* torch.optim.Adam step on a flat buffer (DIFF.py:291, 325; VAE.py:295, 354), coupled
  * L2 weight decay, bias correction for step number `step` (1-based). */
 int tad_adam_step(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,

@@ -301,6 +301,24 @@ def convert_case(ref, name, schema, B, T, seed):
                         meta=fu.pack_meta(dict(schema=schema, B=B, T=T, seed=seed)), **save)
 
 
+def windows_case(ref, name, rows, F, seq_len, stride, B, seed):
+    """dataprovider_pypots.sliding_window (dataprovider_pypots.py:75-87) on a seeded table, plus the minibatch the
+    trainers take from its result by list indexing (DIFF.py:320, VAE.py:340-348)."""
+    import random
+    import torch
+    sys.path.insert(0, ref)
+    import dataprovider_pypots as dpp          # needs the pygrinder stand-in import_reference() installs
+    rng = np.random.default_rng(seed)
+    table = rng.standard_normal((rows, F)).astype(np.float32)
+    stacked = dpp.sliding_window(torch.from_numpy(table), seq_len, stride)
+    random.seed(seed)
+    idx = random.sample(range(stacked.shape[0]), B)
+    batch = stacked[idx]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), table=table, stacked=stacked.numpy(), idx=np.asarray(idx, np.int64),
+                        batch=batch.numpy(), meta=fu.pack_meta(dict(rows=rows, F=F, seq_len=seq_len, stride=stride, B=B, seed=seed)))
+    print(name, tuple(stacked.shape))
+
+
 def schedule_case(DIFF):
     np.savez_compressed(os.path.join(HERE, "schedule.npz"), betas=DIFF.betas.numpy(), alphas=DIFF.alphas.numpy())
 
@@ -308,12 +326,17 @@ def schedule_case(DIFF):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'convert': write only the convert_to_tensor fixtures")
+    ap.add_argument("--only", default="", help="'convert' / 'windows': write only those fixtures")
     a = ap.parse_args()
     DIFF, VAE = import_reference(a.ref)
     import torch
     torch.set_num_threads(4)
     S = fu.SCHEMAS
+    windows_case(a.ref, "windows_stride1", rows=60, F=8, seq_len=24, stride=1, B=16, seed=71)
+    windows_case(a.ref, "windows_stride12", rows=131, F=13, seq_len=48, stride=12, B=5, seed=72)
+    windows_case(a.ref, "windows_exact", rows=24, F=3, seq_len=24, stride=5, B=1, seed=73)
+    if a.only == "windows":
+        return
     convert_case(a.ref, "convert_mixed", S["mixed"], B=6, T=8, seed=61)
     convert_case(a.ref, "convert_metro", S["metro"], B=5, T=6, seed=62)
     convert_case(a.ref, "convert_numeric", S["numeric"], B=4, T=5, seed=63)

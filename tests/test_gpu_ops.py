@@ -678,3 +678,45 @@ def test_rnn_single_sequence_and_maximum_hidden_size(ops, dev, cell):
     r = _run_rnn(ops, dev, cell, 1, B, T, H, [False], np.random.default_rng(11), IN=16)
     assert r["s16"]
     _check_rnn(r, cell, B, T, H, BF16_EMU_TOL)
+
+
+# ---------------------------------------------------------------------------- sliding windows on the device
+@pytest.mark.parametrize("name", ["windows_stride1", "windows_stride12", "windows_exact"])
+def test_sliding_window_vs_reference_golden(ops, dev, name):
+    """tad_gather_windows through the reference-signature wrapper and the un-materialised WindowedTable:
+    bit-exact against the reference's stacked tensor and its indexed minibatch."""
+    from timeautodiff_amd import dataprovider_pypots as dpp
+    z, meta = fu.load(name)
+    T, stride = meta["seq_len"], meta["stride"]
+    stacked = dpp.sliding_window(D(z["table"], dev), T, stride)
+    assert stacked.shape == z["stacked"].shape and np.array_equal(stacked.cpu().numpy(), z["stacked"])
+    wt = dpp.WindowedTable(torch.from_numpy(z["table"]), T, stride, device=dev)      # host table: copied once
+    assert tuple(wt.shape) == z["stacked"].shape and len(wt) == z["stacked"].shape[0]
+    batch = wt.gather(torch.from_numpy(z["idx"]))
+    assert np.array_equal(batch.cpu().numpy(), z["batch"])
+    with pytest.raises(IndexError):
+        wt.gather(torch.tensor([len(wt)]))
+    # 1-D series and a table whose width rules out 16-byte accesses
+    s1 = dpp.sliding_window(D(z["table"][:, 0].copy(), dev), T, stride)
+    assert np.array_equal(s1.cpu().numpy(), z["stacked"][:, :, 0])
+    odd = dpp.sliding_window(D(z["table"][:, :3].copy(), dev), T, stride)
+    assert np.array_equal(odd.cpu().numpy(), z["stacked"][:, :, :3])
+
+
+def test_gather_windows_fullsize_vs_oracle(ops, dev):
+    """Bench-sized table (stride 1, T = 24, 42 columns): every window of a random minibatch equals the oracle's,
+    and the windows overlap as they must (row t+1 of window i is row t of window i+1)."""
+    from oracle import windows as owin
+    from timeautodiff_amd import dataprovider_pypots as dpp
+    rng = np.random.default_rng(9)
+    rows, F, T = 65536 + 23, 42, 24
+    table = rng.standard_normal((rows, F)).astype(np.float32)
+    wt = dpp.WindowedTable(D(table, dev), T, 1)
+    assert len(wt) == 65536
+    idx = rng.integers(0, len(wt), 4096)
+    got = wt.gather(torch.from_numpy(idx)).cpu().numpy()
+    assert np.array_equal(got, owin.gather_windows(table, idx, T, 1))
+    two = wt.gather(torch.tensor([100, 101])).cpu().numpy()
+    assert np.array_equal(two[0, 1:], two[1, :-1])
+    with pytest.raises(RuntimeError):
+        dpp.WindowedTable(D(table[:5], dev), T, 1)           # fewer rows than one window: the reference's stack([]) error

@@ -219,3 +219,26 @@ def test_convert_to_tensor_matches_reference(name):
     out = oconv.convert_to_tensor(gen, sch["n_bins"], sch["n_cats"], sch["n_nums"], sch["cards"])
     assert out.dtype == np.float32 and out.shape == z["out"].shape
     assert np.array_equal(out, z["out"])
+
+
+# ---------------------------------------------------------------------------- sliding windows
+@pytest.mark.parametrize("name", ["windows_stride1", "windows_stride12", "windows_exact"])
+def test_sliding_window_matches_reference(name):
+    """oracle.windows vs dataprovider_pypots.sliding_window run by the reference, and the minibatch taken from
+    its result by index: exact copies."""
+    from oracle import windows as owin
+    z, meta = fu.load(name)
+    stacked = owin.sliding_window(z["table"], meta["seq_len"], meta["stride"])
+    assert stacked.shape == z["stacked"].shape and np.array_equal(stacked, z["stacked"])
+    batch = owin.gather_windows(z["table"], z["idx"], meta["seq_len"], meta["stride"])
+    assert np.array_equal(batch, z["batch"])
+
+
+def test_num_windows_follows_the_reference_loop():
+    from oracle import windows as owin
+    from timeautodiff_amd.dataprovider_pypots import num_windows
+    for rows in (1, 5, 24, 25, 60, 131):
+        for T in (1, 5, 24, 48):
+            for stride in (1, 5, 12, 100):
+                want = len(owin.sliding_window(np.zeros((rows, 1)), T, stride)) if rows >= T else 0
+                assert num_windows(rows, T, stride) == want, (rows, T, stride)

@@ -185,6 +185,25 @@ def get_loss(model, x, t, time_info, cond=None, target_mask=None, *, i=None, noi
 
 
 # ---------------------------------------------------------------------------
+def _stage(data, d):
+    """Device-resident form of a per-window dataset: a contiguous fp32 [N, T, F] tensor or a WindowedTable."""
+    from .dataprovider_pypots import WindowedTable
+    if isinstance(data, WindowedTable):
+        di = lambda x: x.index if x.index is not None else torch.cuda.current_device()     # noqa: E731
+        if data.device.type != torch.device(d).type or di(data.device) != di(torch.device(d)):
+            raise ValueError(f"WindowedTable lives on {data.device}, the trainer on {d}")
+        return data
+    return data.to(device=d, dtype=torch.float32).contiguous()
+
+
+def _gather(data, idx, out):
+    """Minibatch rows idx of a staged dataset (indices come from a draw over range(N): in range by construction)."""
+    if isinstance(data, torch.Tensor):
+        ops.gather_rows(data, idx, out)
+    else:
+        data.gather_unchecked(idx, out)
+
+
 class DiffusionTrainer:
     """One-GPU-per-process training state of the denoiser: device-resident dataset, flat
     parameters/gradients/Adam moments, per-step draws, optional data-parallel plan."""
@@ -196,8 +215,10 @@ class DiffusionTrainer:
         self.eng = model.engine(dev)
         d = self.eng.device
         self.x = latent.detach().to(device=d, dtype=torch.float32).contiguous()
-        self.time_info = time_info.to(device=d, dtype=torch.float32).contiguous()
-        self.cond = cond.to(device=d, dtype=torch.float32).contiguous()
+        # time_info / cond: the reference's stacked [N, T, F] tensors, or WindowedTable views of the tables they
+        # are cut from (dataprovider_pypots.py:302-308) -- then the stacked form never exists
+        self.time_info = _stage(time_info, d)
+        self.cond = _stage(cond, d)
         self.N, self.T, self.K = self.x.shape
         self.B = batch_size if batch_size is not None else model.cfg["diffusion_steps"]
         self.lr = lr
@@ -250,8 +271,8 @@ class DiffusionTrainer:
         i_idx = dr["i"][lo:hi].to(d, dtype=torch.int32, non_blocking=True).contiguous()
         noise = dr["noise"][lo:hi].to(d, dtype=torch.float32, non_blocking=True).contiguous()
         ops.gather_rows(self.x, idx, self.bx)
-        ops.gather_rows(self.time_info, idx, self.bt)
-        ops.gather_rows(self.cond, idx, self.bc)
+        _gather(self.time_info, idx, self.bt)
+        _gather(self.cond, idx, self.bc)
         eng.fp.zero_grad()
         self.loss_sum.zero_()
         eng.loss_and_grads(self.bx, t, i_idx, noise, self.bt, self.bc, self.alphas, self.loss_sum,

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "tad_layernorm_fwd": (_i, [_i64, _i, _p, _i64, _p, _p, _f, _p, _i64, _p, _p]),
     "tad_layernorm_bwd": (_i, [_i64, _i, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
     "tad_gather_rows": (_i, [_i64, _i64, _p, _p, _p, _p]),
+    "tad_gather_windows": (_i, [_i64, _i64, _i64, _i64, _p, _i64, _p, _p, _p]),
     "tad_adam_step": (_i, [_i64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
     "tad_vae_reparam_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _p]),
     "tad_vae_reparam_bwd": (_i, [_i64, _p, _p, _p, _p, _f, _p, _p, _p]),

@@ -258,6 +258,24 @@ __global__ void gather_rows_kernel(int64_t rows, int64_t len, const float* __res
   }
 }
 
+// Window gather: out[b, t, :] = table[idx[b] * stride + t, :] (windows of a [rows, F] table, never materialised).
+// One thread per 16 bytes when F, ld and the bases allow it, else per element.
+template <bool VEC>
+__global__ void gather_windows_kernel(int64_t B, int T, int F, int64_t stride, const float* __restrict__ table, int64_t ld,
+                                      const int64_t* __restrict__ idx, float* __restrict__ out) {
+  const int fw = VEC ? F / 4 : F;
+  const int64_t n = B * T * fw;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bt = e / fw;
+    const int c = (int)(e - bt * fw);
+    const int64_t b = bt / T;
+    const int t = (int)(bt - b * T);
+    const float* src = table + (idx[b] * stride + t) * ld;
+    if constexpr (VEC) reinterpret_cast<float4*>(out)[e] = reinterpret_cast<const float4*>(src)[c];
+    else out[e] = src[c];
+  }
+}
+
 __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float b1, float b2, float eps, float wd, float step_size,
                             float inv_sqrt_bc2) {
@@ -460,6 +478,22 @@ extern "C" int tad_gather_rows(int64_t rows, int64_t row_len, const float* src, 
   TAD_CHECK(rows >= 0 && row_len > 0 && src && idx && out, "tad_gather_rows: bad arguments");
   if (rows == 0) return TAD_OK;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(rows * row_len)), dim3(EW_BLOCK), 0, EW_STREAM, rows, row_len, src, idx, out);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_gather_windows(int64_t B, int64_t T, int64_t F, int64_t stride, const float* table, int64_t ld,
+                                  const int64_t* idx, float* out, tad_stream_t stream) {
+  TAD_CHECK(B >= 0 && T > 0 && F > 0 && stride > 0 && ld >= F && T < (1 << 30) && F < (1 << 30) && table && idx && out,
+            "tad_gather_windows: bad arguments B=%ld T=%ld F=%ld stride=%ld ld=%ld", (long)B, (long)T, (long)F, (long)stride, (long)ld);
+  if (B == 0) return TAD_OK;
+  const bool vec = F % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(table) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(gather_windows_kernel<true>, dim3(ew_grid(B * T * (F / 4))), dim3(EW_BLOCK), 0, EW_STREAM, B, (int)T, (int)F, stride,
+                       table, ld, idx, out);
+  else
+    hipLaunchKernelGGL(gather_windows_kernel<false>, dim3(ew_grid(B * T * F)), dim3(EW_BLOCK), 0, EW_STREAM, B, (int)T, (int)F, stride, table,
+                       ld, idx, out);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

@@ -70,7 +70,7 @@ extern "C" int tad_linear_bwd_weight_b16(int64_t M, int64_t N, int64_t K, const 
   p.atomic = 1; p.shiftT = (int)T; p.shift = T > 0 ? (int)tshift : 0;
   p.rowsum = db; p.rowsum2 = db2;
   TAD_CHECK(set_gate_map(p, gate_map, N), "tad_linear_bwd_weight_b16: bad gate map (N must be a multiple of 4*H, slots < G)");
-  const Cfg cfg = pick_cfg(TAD_BF16, N, K, 0);
+  const Cfg cfg = pick_cfg_bwd_weight(TAD_BF16, N, K);
   const int splits = plan_splits(p, cfg);
   return launch_bf16<RC16, RC32>(cfg, p, splits, (hipStream_t)stream);
 }

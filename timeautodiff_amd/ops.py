@@ -359,6 +359,15 @@ def gather_rows(src, idx, out):
     _call("tad_gather_rows", rows, row_len, src.data_ptr(), idx.data_ptr(), out.data_ptr(), _stream())
 
 
+def gather_windows(table, idx, T, stride, out):
+    """out[b, t, :] = table[idx[b] * stride + t, :]: a minibatch of sliding windows cut on the fly from the
+    [rows, F] table (reference dataprovider_pypots.py:75-87 + the trainers' index gather); idx int64 on device."""
+    assert table.dim() == 2 and table.stride(1) == 1 and out.is_contiguous() and idx.dtype == torch.int64 and idx.is_cuda
+    B, F = idx.numel(), table.shape[1]
+    assert out.numel() == B * T * F
+    _call("tad_gather_windows", B, T, F, stride, table.data_ptr(), table.stride(0), idx.data_ptr(), out.data_ptr(), _stream())
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n
