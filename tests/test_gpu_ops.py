@@ -93,7 +93,7 @@ def test_linear_bwd_data(ops, dev, prec, M, N, K):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("M,N,K", SHAPES + [(4096, 96, 40)])
+@pytest.mark.parametrize("M,N,K", SHAPES + [(4096, 96, 40), (8192, 8, 400), (8191, 200, 6), (3, 2, 1100)])
 def test_linear_bwd_weight(ops, dev, prec, M, N, K):
     rng = np.random.default_rng(M + 7 * N + K)
     dY = rnd(rng, M, N)
@@ -720,3 +720,23 @@ def test_gather_windows_fullsize_vs_oracle(ops, dev):
     assert np.array_equal(two[0, 1:], two[1, :-1])
     with pytest.raises(RuntimeError):
         dpp.WindowedTable(D(table[:5], dev), T, 1)           # fewer rows than one window: the reference's stack([]) error
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_linear_bwd_weight_skinny_strided_operands(ops, dev, prec):
+    """Extents <= 8 on either side (input_proj, fc, time_encode) with operands that are column slices of wider
+    buffers (leading dimension > extent), result accumulated into a slice of a wider dW."""
+    rng = np.random.default_rng(31)
+    M = 1000
+    for N, K in ((6, 130), (130, 8)):
+        dYb, Xb = rnd(rng, M, N + 11), rnd(rng, M, K + 5)
+        dY, X = dYb[:, 3:3 + N], Xb[:, 2:2 + K]
+        dYr, Xr = (bf16_round(dY), bf16_round(X)) if prec else (dY, X)
+        ref = dYr.astype(np.float64).T @ Xr.astype(np.float64)
+        dWb = torch.full((N, K + 7), 0.25, device=dev)
+        db = torch.zeros(N, device=dev)
+        ops.linear_bwd_weight(prec, D(dYb, dev)[:, 3:3 + N], D(Xb, dev)[:, 2:2 + K], dWb[:, 4:4 + K], db=db)
+        got = dWb.cpu().numpy()
+        assert fu.rel_err(got[:, 4:4 + K], ref + 0.25) < F32_TOL
+        assert np.all(got[:, :4] == 0.25) and np.all(got[:, 4 + K:] == 0.25)
+        assert fu.rel_err(db.cpu().numpy(), dY.astype(np.float64).sum(0)) < F32_TOL

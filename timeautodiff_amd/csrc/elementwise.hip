@@ -179,32 +179,58 @@ __global__ void silu_bwd_kernel(int64_t n, const float* __restrict__ z, const fl
   }
 }
 
-// one wave per row
+// One wave per row; the row lives in registers (NC = ceil(D / 64) elements per lane), so x is read once.
+// Sums run over the lane's elements in column order, then across the wave: two-pass mean / variance.
+template <int NC>
 __global__ void layernorm_fwd_kernel(int64_t rows, int D, const float* __restrict__ x, int64_t ldx,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                      float* __restrict__ y, int64_t ldy, float* __restrict__ mr) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float gm[NC], bt[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    gm[i] = c < D ? gamma[c] : 0.f;
+    bt[i] = c < D ? beta[c] : 0.f;
+  }
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float* xr = x + r * ldx;
+    float xv[NC];
     float s = 0.f;
-    for (int c = lane; c < D; c += 64) s += xr[c];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = c < D ? xr[c] : 0.f;
+      if (c < D) s += xv[i];
+    }
     const float mean = wave_sum(s) / (float)D;
     float v = 0.f;
-    for (int c = lane; c < D; c += 64) { const float dlt = xr[c] - mean; v += dlt * dlt; }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const float dlt = xv[i] - mean;
+      if (lane + 64 * i < D) v += dlt * dlt;
+    }
     const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
-    for (int c = lane; c < D; c += 64) y[r * ldy + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) y[r * ldy + c] = (xv[i] - mean) * rstd * gm[i] + bt[i];
+    }
     if (mr && lane == 0) { mr[2 * r] = mean; mr[2 * r + 1] = rstd; }
   }
 }
 
+// One wave per row.  The column sums (dgamma, dbeta) are kept per lane over the wave's rows, combined over
+// the workgroup's waves in LDS, and added to the result with one atomic per column and workgroup.
 template <int NC>
 __global__ void layernorm_bwd_kernel(int64_t rows, int D, const float* __restrict__ dy, int64_t lddy,
                                      const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                      const float* __restrict__ mr, float* __restrict__ dx, int64_t lddx,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int lane = threadIdx.x & 63;
+  __shared__ float red[2][NC * 64];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nwb = blockDim.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   float dg[NC], db[NC], gm[NC];
@@ -239,13 +265,20 @@ __global__ void layernorm_bwd_kernel(int64_t rows, int D, const float* __restric
       if (c < D) dx[r * lddx + c] = rstd * (dxh[i] - m1 - xh[i] * m2);
     }
   }
+  for (int w = 0; w < nwb; ++w) {       // waves take turns adding their sums into the LDS rows
+    if (wib == w) {
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = lane + 64 * i;
-    if (c < D) {
-      atomicAdd(&dgamma[c], dg[i]);
-      atomicAdd(&dbeta[c], db[i]);
+      for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        red[0][c] = (w ? red[0][c] : 0.f) + dg[i];
+        red[1][c] = (w ? red[1][c] : 0.f) + db[i];
+      }
     }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    atomicAdd(&dgamma[c], red[0][c]);
+    atomicAdd(&dbeta[c], red[1][c]);
   }
 }
 
@@ -447,9 +480,15 @@ extern "C" int tad_layernorm_fwd(int64_t rows, int D, const float* x, int64_t ld
   TAD_CHECK(rows >= 0 && D > 0 && x && gamma && beta && y && ldx >= D && ldy >= D, "tad_layernorm_fwd: bad arguments");
   if (rows == 0) return TAD_OK;
   int64_t g = cdiv64(rows, EW_BLOCK / 64);
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)g), dim3(EW_BLOCK), 0, EW_STREAM, rows, D, x, ldx, gamma, beta, eps, y,
-                     ldy, mean_rstd);
+  if (g > 4096) g = 4096;
+  const int nc = (int)cdiv64(D, 64);
+  TAD_CHECK(nc <= 32, "tad_layernorm_fwd: D = %d too large (<= 2048)", D);
+#define LN_FWD(NC) hipLaunchKernelGGL(layernorm_fwd_kernel<NC>, dim3((unsigned)g), dim3(EW_BLOCK), 0, EW_STREAM, rows, D, x, ldx, gamma, beta, eps, y, ldy, mean_rstd)
+  if (nc <= 2) LN_FWD(2);
+  else if (nc <= 8) LN_FWD(8);
+  else if (nc <= 16) LN_FWD(16);
+  else LN_FWD(32);
+#undef LN_FWD
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }
@@ -461,7 +500,7 @@ extern "C" int tad_layernorm_bwd(int64_t rows, int D, const float* dy, int64_t l
   TAD_CHECK(lddy >= D && ldx >= D && lddx >= D, "tad_layernorm_bwd: bad leading dimension");
   if (rows == 0) return TAD_OK;
   int64_t g = cdiv64(rows, EW_BLOCK / 64);
-  if (g > 512) g = 512;
+  if (g > 2048) g = 2048;
   const int nc = (int)cdiv64(D, 64);
 #define LN_BWD(NC) hipLaunchKernelGGL(layernorm_bwd_kernel<NC>, dim3((unsigned)g), dim3(EW_BLOCK), 0, EW_STREAM, rows, D, dy, lddy, x, ldx, gamma, mean_rstd, dx, lddx, dgamma, dbeta)
   if (nc <= 2) LN_BWD(2);

@@ -74,39 +74,50 @@ __global__ void pack_kernel(PackArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// acc[n] += A(32 x K from LDS) * B(block stream): blocks ordered [kk][n], 64 uint4 each.
+// acc[n] += A(32 x K from LDS) * B(block stream): blocks ordered [kk][n], 64 uint4 each.  The first kl k-blocks
+// are read from a copy of theirs in LDS (wl, same order), the rest from global memory through a ring of PF
+// k-blocks in registers; the ring's first loads are issued before the LDS part, which hides their latency.
 template <bool BF16, int NT, int PF>
 __device__ __forceinline__ void mma_stream(f32x16* acc, const unsigned char* lds_a, int lds_ld,
-                                           const uint4* __restrict__ wp, int nk, int lane) {
+                                           const uint4* __restrict__ wp, int nk, int lane, const uint4* wl = nullptr, int kl = 0) {
   const int row = lane & 31, half = lane >> 5;
+  auto step = [&](int kk, const uint4* bsrc) {
+    if constexpr (BF16) {
+      const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_a + ((size_t)row * lds_ld + 16 * kk + 8 * half) * 2);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const bf16x8 bv = __builtin_bit_cast(bf16x8, bsrc[n]);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[n], 0, 0, 0);
+      }
+    } else {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(lds_a + ((size_t)row * lds_ld + 8 * kk + 4 * half) * 4);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const f32x4 bv = __builtin_bit_cast(f32x4, bsrc[n]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[n], 0, 0, 0);
+      }
+    }
+  };
   uint4 ring[PF][NT];
 #pragma unroll
   for (int p = 0; p < PF; ++p)
-    if (p < nk) {
+    if (kl + p < nk) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) ring[p][n] = wp[((int64_t)p * NT + n) * 64 + lane];
+      for (int n = 0; n < NT; ++n) ring[p][n] = wp[((int64_t)(kl + p) * NT + n) * 64 + lane];
     }
-  for (int kk0 = 0; kk0 < nk; kk0 += PF) {
+  for (int kk = 0; kk < kl; ++kk) {
+    uint4 b[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b[n] = wl[(kk * NT + n) * 64 + lane];
+    step(kk, b);
+  }
+  for (int kk0 = kl; kk0 < nk; kk0 += PF) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const int kk = kk0 + p;
       if (kk < nk) {
-        if constexpr (BF16) {
-          const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_a + ((size_t)row * lds_ld + 16 * kk + 8 * half) * 2);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const bf16x8 bv = __builtin_bit_cast(bf16x8, ring[p][n]);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[n], 0, 0, 0);
-          }
-        } else {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(lds_a + ((size_t)row * lds_ld + 8 * kk + 4 * half) * 4);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const f32x4 bv = __builtin_bit_cast(f32x4, ring[p][n]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[n], 0, 0, 0);
-          }
-        }
+        step(kk, ring[p]);
         if (kk + PF < nk) {
 #pragma unroll
           for (int n = 0; n < NT; ++n) ring[p][n] = wp[((int64_t)(kk + PF) * NT + n) * 64 + lane];
@@ -157,6 +168,7 @@ __device__ __forceinline__ float bf16_rt(float v) {
 struct RnnFwdArgs {
   tad_rnn_dir_t d[MAXDIR];
   int B, T, H, NJ, nk, lds_ld, rpw;
+  int kl;      // leading k-blocks of every chunk's W_hh image kept in LDS for the whole sequence
 };
 
 template <int CELL, bool BF16, bool ST16, int JPW>
@@ -177,6 +189,12 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
   const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed);
 
   for (size_t i = threadIdx.x; i < 2 * buf_bytes / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  // W_hh is the same every step: the part of the wave's chunk image that fits the LDS beside the two h
+  // buffers is copied there once; only the rest is streamed from L2 each step (JPW == 1 only)
+  uint4* wl = reinterpret_cast<uint4*>(smem + 2 * buf_bytes) + (size_t)wave * a.kl * G * 64;
+  if (JPW == 1 && wave < a.NJ) {
+    for (int i = 0; i < a.kl * G; ++i) wl[i * 64 + lane] = wp[((int64_t)wave * a.nk * G + i) * 64 + lane];
+  }
 
   float st[JPW][16];   // LSTM: c; GRU: h
   float bh[JPW][3];
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
           load_xp(step, jj, raw);
           seed(raw, acc, xn);
         }
-        mma_stream<BF16, G, PF>(acc, cur, a.lds_ld, wp + (int64_t)j * a.nk * G * 64, a.nk, lane);
+        mma_stream<BF16, G, PF>(acc, cur, a.lds_ld, wp + (int64_t)j * a.nk * G * 64, a.nk, lane, wl, JPW == 1 ? a.kl : 0);
         if constexpr (PREFETCH) {
           if (step + 1 < T) load_xp(step + 1, 0, nraw);
         }
@@ -642,8 +660,18 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   a.B = (int)B; a.T = (int)T; a.H = (int)H; a.NJ = g.NJ; a.nk = g.nkf;
   a.rpw = rows_per_wg(B, ndir);
   a.lds_ld = g.width + (bf ? 8 : 4);
-  const size_t lds = (size_t)2 * 32 * a.lds_ld * (bf ? 2 : 4);
+  size_t lds = (size_t)2 * 32 * a.lds_ld * (bf ? 2 : 4);
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_fwd: H=%ld needs %zu bytes of LDS in this precision (limit %zu)", (long)H, lds, LDS_LIMIT);
+  a.kl = 0;
+  if (g.jpw == 1) {
+    static const char* force = getenv("TAD_RNN_KL");      // experiments: k-blocks of W_hh kept in LDS
+    const size_t per_kl = (size_t)g.NJ * G * 1024;
+    int64_t kl = (int64_t)((LDS_LIMIT - lds) / per_kl);
+    if (kl > g.nkf) kl = g.nkf;
+    if (force && atoi(force) < kl) kl = atoi(force);
+    a.kl = (int)kl;
+    lds += (size_t)a.kl * per_kl;
+  }
   dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
 #define TAD_FWD(C, BFV, STV)                                                              \
