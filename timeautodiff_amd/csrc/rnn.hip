@@ -14,6 +14,7 @@
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = batch row within the tile.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -81,16 +82,19 @@ template <bool BF16, int NT, int PF>
 __device__ __forceinline__ void mma_stream(f32x16* acc, const unsigned char* lds_a, int lds_ld,
                                            const uint4* __restrict__ wp, int nk, int lane, const uint4* wl = nullptr, int kl = 0) {
   const int row = lane & 31, half = lane >> 5;
-  auto step = [&](int kk, const uint4* bsrc) {
+  typedef typename std::conditional<BF16, bf16x8, f32x4>::type afrag_t;
+  auto afrag = [&](int kk) -> afrag_t {
+    if constexpr (BF16) return *reinterpret_cast<const bf16x8*>(lds_a + ((size_t)row * lds_ld + 16 * kk + 8 * half) * 2);
+    else return *reinterpret_cast<const f32x4*>(lds_a + ((size_t)row * lds_ld + 8 * kk + 4 * half) * 4);
+  };
+  auto mma = [&](afrag_t av, const uint4* bsrc) {
     if constexpr (BF16) {
-      const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_a + ((size_t)row * lds_ld + 16 * kk + 8 * half) * 2);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const bf16x8 bv = __builtin_bit_cast(bf16x8, bsrc[n]);
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[n], 0, 0, 0);
       }
     } else {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(lds_a + ((size_t)row * lds_ld + 8 * kk + 4 * half) * 4);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const f32x4 bv = __builtin_bit_cast(f32x4, bsrc[n]);
@@ -107,17 +111,23 @@ __device__ __forceinline__ void mma_stream(f32x16* acc, const unsigned char* lds
       for (int n = 0; n < NT; ++n) ring[p][n] = wp[((int64_t)(kl + p) * NT + n) * 64 + lane];
     }
   for (int kk = 0; kk < kl; ++kk) {
+    const afrag_t av = afrag(kk);
     uint4 b[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) b[n] = wl[(kk * NT + n) * 64 + lane];
-    step(kk, b);
+    mma(av, b);
   }
+  // the A fragments of a whole ring round are fetched together, so their LDS latency is paid once per
+  // round instead of once per k-block (indices beyond nk re-read block nk - 1, unused)
   for (int kk0 = kl; kk0 < nk; kk0 += PF) {
+    afrag_t av[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) av[p] = afrag(kk0 + p < nk ? kk0 + p : nk - 1);
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const int kk = kk0 + p;
       if (kk < nk) {
-        step(kk, ring[p]);
+        mma(av[p], ring[p]);
         if (kk + PF < nk) {
 #pragma unroll
           for (int n = 0; n < NT; ++n) ring[p][n] = wp[((int64_t)(kk + PF) * NT + n) * 64 + lane];

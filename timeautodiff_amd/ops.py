@@ -12,7 +12,14 @@ from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, BF16, CELL_GRU, CELL_LSTM, F32, RnnBwdDir, RnnDir  # noqa: F401
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw handle of torch's current HIP stream on the current device (the fast C accessor when this torch has
+    it: the Python-level lookup costs several microseconds per launch, 84 launches per training step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
