@@ -431,9 +431,9 @@ def test_train_diffusion_on_windowed_tables_equals_stacked_tensors(dev):
         losses = []
         model = DIFF.train_diffusion(torch.from_numpy(latent), None, dd, H, 2, 100, steps, losses=losses)
         runs.append((losses, {k: v.cpu().numpy().copy() for k, v in model.state_dict().items()}))
-    # the forward pass is deterministic: the first loss is bit-identical; weight gradients are accumulated with
-    # float atomics (summation order varies from run to run), so later steps agree to rounding, 1e-5 relative
-    assert runs[0][0][0] == runs[1][0][0]
+    # same windows, same draws: the runs differ only by the summation order of float atomics (the loss sum,
+    # the split reductions of the weight gradients), i.e. by rounding: 1e-6 on the first loss, 1e-5 on the curve
+    assert abs(runs[0][0][0] - runs[1][0][0]) < 1e-6 * abs(runs[0][0][0])
     assert np.max(np.abs(np.array(runs[0][0]) - np.array(runs[1][0])) / np.abs(np.array(runs[0][0]))) < 1e-5
     for k in runs[0][1]:
         assert fu.rel_err(runs[1][1][k], runs[0][1][k]) < 1e-4, k

@@ -133,7 +133,7 @@ __device__ __forceinline__ void lds_store_run(unsigned char* lds, int row, int k
 // Addresses are a wave-uniform base (scalar registers) plus a 32-bit per-lane offset.
 // VEC: rows 16-byte aligned and the k range a multiple of 4 -> one 16-byte load per row
 template <int R, int NT, bool VEC>
-__device__ __forceinline__ void load_kc(float* reg, const float* __restrict__ P, int64_t s_row, int64_t row0,
+__device__ __forceinline__ void load_kc(float* reg, const float* __restrict__ slab, int64_t s_row, int64_t row0,
                                         int64_t rows, int64_t k0, int64_t kend, int tid) {
   constexpr int ITS = R * 8 / NT;
   static_assert(ITS >= 1 && R * 8 % NT == 0, "tile rows vs threads");
@@ -141,7 +141,7 @@ __device__ __forceinline__ void load_kc(float* reg, const float* __restrict__ P,
   const int64_t krem64 = kend - k0, nrow64 = rows - row0;
   const int krem = (int)(krem64 < BK ? krem64 : BK);
   const int nrow1 = (int)(nrow64 < R ? nrow64 : R) - 1;
-  const float* base = P + row0 * s_row + k0;
+  const float* base = slab;            // element (row0, k0): the kernel advances it from slab to slab
 #pragma unroll
   for (int it = 0; it < ITS; ++it) {
     int row = r + (NT / 8) * it;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void store_kc(float* reg, unsigned char* lds, int64_t
 // chunks of 16 bytes per row; thread -> rows tid/4 + (NT/4)*it, chunk tid%4.  No conversion: the
 // chunk goes to LDS as it is.  Needs 16-byte aligned rows and a reduction length that is a multiple of 8.
 template <int R, int NT>
-__device__ __forceinline__ void load_kc16(uint4* reg, const bf16_t* __restrict__ P, int64_t s_row, int64_t row0,
+__device__ __forceinline__ void load_kc16(uint4* reg, const bf16_t* __restrict__ slab, int64_t s_row, int64_t row0,
                                           int64_t rows, int64_t k0, int64_t kend, int tid) {
   constexpr int ITS = R * 4 / NT;
   static_assert(ITS >= 1 && R * 4 % NT == 0, "tile rows vs threads");
@@ -189,7 +189,7 @@ __device__ __forceinline__ void load_kc16(uint4* reg, const bf16_t* __restrict__
   const int krem = (int)(krem64 < BK ? krem64 : BK);
   const int nrow1 = (int)(nrow64 < R ? nrow64 : R) - 1;
   const int kq = (8 * c + 8 <= krem) ? 8 * c : 0;
-  const bf16_t* base = P + row0 * s_row + k0;
+  const bf16_t* base = slab;
 #pragma unroll
   for (int it = 0; it < ITS; ++it) {
     int row = r + (NT / 4) * it;
@@ -220,7 +220,7 @@ __device__ __forceinline__ void store_kc16(uint4* reg, unsigned char* lds, int64
 template <int R> constexpr int tr_stride() { return R * 2 + 64; }
 
 template <int R, int NT>
-__device__ __forceinline__ uint32_t load_rc16(uint4* reg, const bf16_t* __restrict__ P, int64_t s_k, int64_t row0,
+__device__ __forceinline__ uint32_t load_rc16(uint4* reg, const bf16_t* __restrict__ slab, int64_t s_k, int64_t row0,
                                               int64_t rows, int64_t k0, int64_t kend, int tid) {
   constexpr int CH = R / 8, KPP = NT / CH, ITS = BK / KPP;
   static_assert(NT % CH == 0 && KPP >= 1 && BK % KPP == 0 && ITS >= 1, "tile rows vs threads");
@@ -229,7 +229,7 @@ __device__ __forceinline__ uint32_t load_rc16(uint4* reg, const bf16_t* __restri
   const int nch1 = (int)(nrow64 < R ? nrow64 : R) / 8 - 1;
   const int chc = ch < nch1 ? ch : nch1;
   const int krem = (int)(krem64 < BK ? krem64 : BK);
-  const bf16_t* base = P + row0 + k0 * s_k;
+  const bf16_t* base = slab;
   uint32_t okbits = 0;
 #pragma unroll
   for (int it = 0; it < ITS; ++it) {
@@ -282,9 +282,13 @@ __device__ __forceinline__ bf16x8 tr_fragment(const unsigned char* img, uint32_t
 // the row count to be multiples of 4 and a 16-byte aligned base.  reg[4*e + i] = (row 4*rq + i, k e).
 // Scalar form: thread -> row tid % R and 32*R/NT consecutive k, one dword load each.
 // Both return the bit mask of the thread's k positions that hold real data.
+// `tpos` = k0 mod shiftT and `kbm` = (the thread's first k inside the tile) mod shiftT come from the caller, which
+// keeps them up incrementally: everything per k position is a handful of scalar operations (no division, no
+// 64-bit products), and the loads are a wave-uniform k-row pointer plus one loop-invariant per-lane offset.
 template <int R, int NT>
-__device__ __forceinline__ uint32_t load_rc4(float* reg, const float* __restrict__ P, int64_t s_k, int64_t row0,
-                                             int64_t rows, int64_t k0, int64_t kend, int tid, int shiftT, int shift) {
+__device__ __forceinline__ uint32_t load_rc4(float* reg, const float* __restrict__ slab, int64_t s_k, int64_t row0,
+                                             int64_t rows, int64_t k0, int64_t kend, int tid, int shiftT, int shift, int tpos,
+                                             int kbm) {
   constexpr int RQ = R / 4, KG = NT / RQ, KPT = BK / KG;
   static_assert(NT % RQ == 0 && BK % KG == 0 && KPT >= 2, "tile rows vs threads");
   const int rq = tid % RQ;
@@ -294,25 +298,32 @@ __device__ __forceinline__ uint32_t load_rc4(float* reg, const float* __restrict
   const int rqc = rq < nq1 ? rq : nq1;
   const int kb = kg * KPT;
   const int64_t krem64 = kend - k0 - kb;
-  const int kl = (int)(krem64 < KPT ? krem64 : KPT);
-  int t = shiftT > 0 ? (int)((uint32_t)(k0 + kb) % (uint32_t)shiftT) : 0;    // position inside the window of shiftT rows
-  const int sh0 = shift < 0 ? shift : 0;
-  const float* base = P + row0 + (k0 + sh0) * s_k;       // offsets from here are never negative
+  const int kl = (int)(krem64 < KPT ? krem64 : KPT);         // <= 0: nothing of this thread's k range is real
+  const uint32_t Tw = shiftT > 0 ? (uint32_t)shiftT : 0x7fffffffu;
+  int t = tpos + kbm;                                        // position inside the window of shiftT rows
+  if (shiftT > 0 && t >= shiftT) t -= shiftT;
+  const float* first = slab;                                 // k-row k0 always exists: what invalid positions read
+  const float* base = slab + (int64_t)(kb + shift) * s_k;
+  const uint32_t voff = 4u * (uint32_t)rqc;
   uint32_t okbits = 0;
 #pragma unroll
   for (int e = 0; e < KPT; ++e) {
-    bool ok = e < kl;
-    if (shiftT > 0) {
-      const int ts = t + shift;
-      ok = ok && ts >= 0 && ts < shiftT;
-      if (++t == shiftT) t = 0;
-    }
-    const int kk = (ok ? kb + e + shift : 0) - sh0;          // invalid positions read row k0 of P, which exists
-    const float4 v = *reinterpret_cast<const float4*>(base + ((uint32_t)kk * (uint32_t)s_k + 4u * (uint32_t)rqc));
+    const bool ok = (e < kl) & ((uint32_t)(t + shift) < Tw);
+    const float* src = ok ? base + e * s_k : first;
+    const float4 v = *reinterpret_cast<const float4*>(src + voff);
     reg[4 * e + 0] = v.x; reg[4 * e + 1] = v.y; reg[4 * e + 2] = v.z; reg[4 * e + 3] = v.w;
     okbits |= ok ? (1u << e) : 0u;
+    t = (t + 1 == shiftT) ? 0 : t + 1;
   }
   return okbits;
+}
+
+// (the thread's first k inside the tile) mod shiftT, for load_rc4
+template <int R, int NT>
+__device__ __forceinline__ int rc4_kbm(int tid, int shiftT) {
+  constexpr int RQ = R / 4, KG = NT / RQ, KPT = BK / KG;
+  const int kg = (RQ % 64 == 0) ? __builtin_amdgcn_readfirstlane(tid / RQ) : tid / RQ;
+  return shiftT > 0 ? (kg * KPT) % shiftT : 0;
 }
 
 template <bool BF16, int R, int NT>
@@ -334,7 +345,7 @@ __device__ __forceinline__ void store_rc4(float* reg, uint32_t okbits, unsigned 
 }
 
 template <int R, int NT>
-__device__ __forceinline__ uint32_t load_rc1(float* reg, const float* __restrict__ P, int64_t s_k, int64_t row0,
+__device__ __forceinline__ uint32_t load_rc1(float* reg, const float* __restrict__ slab, int64_t s_k, int64_t row0,
                                              int64_t rows, int64_t k0, int64_t kend, int tid, int shiftT, int shift) {
   constexpr int KPT = BK * R / NT;
   static_assert(NT % R == 0 && R % 64 == 0 && KPT >= 4 && KPT % 4 == 0, "tile rows vs threads");
@@ -347,7 +358,6 @@ __device__ __forceinline__ uint32_t load_rc1(float* reg, const float* __restrict
   int t = shiftT > 0 ? (int)((uint32_t)kb % (uint32_t)shiftT) : 0;
   const int64_t krem64 = kend - kb;
   const int kl = (int)(krem64 < KPT ? krem64 : KPT);
-  const float* base = P + row0;
   uint32_t okbits = 0;
 #pragma unroll
   for (int e = 0; e < KPT; ++e) {
@@ -357,8 +367,8 @@ __device__ __forceinline__ uint32_t load_rc1(float* reg, const float* __restrict
       ok = ok && ts >= 0 && ts < shiftT;
       if (++t == shiftT) t = 0;
     }
-    const int64_t kidx = ok ? kb + e + shift : k0;          // k0 itself is always a valid row of P
-    reg[e] = (base + kidx * s_k)[(uint32_t)r];
+    const int64_t kidx = ok ? kq * KPT + e + shift : 0;     // relative to k0, which is always a valid row
+    reg[e] = (slab + kidx * s_k)[(uint32_t)r];
     okbits |= ok ? (1u << e) : 0u;
   }
   return okbits;
@@ -547,12 +557,19 @@ struct Stage {
   uint4 r16[NREG16];
   uint32_t ok = 0;
   int64_t kcur = 0;
+  int kbm = 0;
 
+  // once per kernel, before the first load of an operand that is read with a time shift
+  __device__ __forceinline__ void init(int tid, int shiftT) {
+    if constexpr (KIND == RC32 && VEC) kbm = rc4_kbm<R, NT>(tid, shiftT);
+  }
+
+  // `slab` points at element (row0, k0) of the operand
   __device__ __forceinline__ void load(const void* P, int64_t s_row, int64_t s_k, int64_t row0, int64_t rows, int64_t k0,
-                                       int64_t kend, int tid, int shiftT, int shift) {
+                                       int64_t kend, int tid, int shiftT, int shift, int tpos) {
     kcur = k0;
     if constexpr (KIND == KC32) load_kc<R, NT, VEC>(r32, reinterpret_cast<const float*>(P), s_row, row0, rows, k0, kend, tid);
-    else if constexpr (KIND == RC32 && VEC) ok = load_rc4<R, NT>(r32, reinterpret_cast<const float*>(P), s_k, row0, rows, k0, kend, tid, shiftT, shift);
+    else if constexpr (KIND == RC32 && VEC) ok = load_rc4<R, NT>(r32, reinterpret_cast<const float*>(P), s_k, row0, rows, k0, kend, tid, shiftT, shift, tpos, kbm);
     else if constexpr (KIND == RC32) ok = load_rc1<R, NT>(r32, reinterpret_cast<const float*>(P), s_k, row0, rows, k0, kend, tid, shiftT, shift);
     else if constexpr (KIND == KC16) load_kc16<R, NT>(r16, reinterpret_cast<const bf16_t*>(P), s_row, row0, rows, k0, kend, tid);
     else ok = load_rc16<R, NT>(r16, reinterpret_cast<const bf16_t*>(P), s_k, row0, rows, k0, kend, tid);
@@ -616,9 +633,32 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 
   // row-contiguous A only: sums over k of this thread's A rows (RC32: 4 rows in the VEC form, else 1; RC16: 8 rows)
   float rsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool want_rowsum = A_RC && p.rowsum != nullptr && tn == 0;
-  auto gload = [&](int64_t k0) {
-    sa.load(p.A, p.sa_row, p.sa_k, i0, p.M, k0, kend, tid, 0, 0);
-    sb.load(p.B, p.sb_row, p.sb_k, j0, p.N, k0, kend, tid, p.shiftT, p.shift);
+  // position of the next k-slab inside its window of shiftT rows: the slabs are loaded in order.  A load past
+  // the end of the range re-reads the first slab WITH the first slab's position: the shifted rows it touches
+  // must be the ones that exist.
+  sb.init(tid, p.shiftT);
+  const int tpos_first = p.shiftT > 0 ? (int)((uint64_t)kbeg % (uint32_t)p.shiftT) : 0;
+  int tpos = tpos_first;
+  const int bk_mod = p.shiftT > 0 ? BK % p.shiftT : 0;
+  // The k-slabs are loaded in order; their addresses (element (tile row 0, k) of either operand) and k advance
+  // by one slab per real load -- no products in the loop.  real == false: a load past the end of the range,
+  // which re-reads the first slab.
+  constexpr int ESA = (AK == KC16 || AK == RC16) ? 2 : 4, ESB = (BKD == KC16 || BKD == RC16) ? 2 : 4;
+  const unsigned char* const a_first = reinterpret_cast<const unsigned char*>(p.A) + (i0 * p.sa_row + kbeg * p.sa_k) * ESA;
+  const unsigned char* const b_first = reinterpret_cast<const unsigned char*>(p.B) + (j0 * p.sb_row + kbeg * p.sb_k) * ESB;
+  const int64_t a_step = (int64_t)BK * p.sa_k * ESA, b_step = (int64_t)BK * p.sb_k * ESB;
+  const unsigned char* a_next = a_first;
+  const unsigned char* b_next = b_first;
+  int64_t k_next = kbeg;
+  auto gload = [&](bool real) {
+    const int64_t k0 = real ? k_next : kbeg;
+    sa.load(real ? a_next : a_first, p.sa_row, p.sa_k, i0, p.M, k0, kend, tid, 0, 0, 0);
+    sb.load(real ? b_next : b_first, p.sb_row, p.sb_k, j0, p.N, k0, kend, tid, p.shiftT, p.shift, real ? tpos : tpos_first);
+    if (real) {
+      a_next += a_step; b_next += b_step; k_next += BK;
+      tpos += bk_mod;
+      if (tpos >= p.shiftT && p.shiftT > 0) tpos -= p.shiftT;
+    }
   };
   auto lstore = [&](int buf, bool count) {
     unsigned char* As = smem + (size_t)buf * (A_BYTES + B_BYTES);
@@ -655,9 +695,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 
   // registers -- they have a whole step to arrive -- then runs the MFMAs of step t.  Loads are
   // unconditional: beyond the range they re-read its first tile, which nobody looks at.
   STAMP(ts0);
-  gload(kbeg);
+  gload(true);
   lstore(0, true);
-  gload(nt > 1 ? kbeg + BK : kbeg);
+  gload(nt > 1);
   __syncthreads();
   STAMP(ts1);
 #ifdef EXP_STAMPS
@@ -673,7 +713,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 
   for (int t = 0; t < nt; ++t) {
     lstore((t + 1) & 1, t + 1 < nt);    // the other buffer: last read one barrier ago
     STAMP(tC);
-    gload(t + 2 < nt ? kbeg + (int64_t)(t + 2) * BK : kbeg);
+    gload(t + 2 < nt);
     STAMP(tA);
     const unsigned char* Abuf = smem + (size_t)(t & 1) * (A_BYTES + B_BYTES);
     const unsigned char* Bbuf = Abuf + A_BYTES;
