@@ -344,6 +344,28 @@ __device__ __forceinline__ void store_rc4(float* reg, uint32_t okbits, unsigned 
   }
 }
 
+// bf16 precision: the float4 a lane holds per k is 4 consecutive rows of ONE k, which is exactly 8 bytes of the
+// [k][row] image the 16-bit row-contiguous operands use: lanes write consecutive 8-byte pieces of a k-row
+// (conflict-free; the [row][k] image would put every lane's rows 256 bytes apart, on the same banks) and the
+// fragments come out through the transposing LDS read, with no transposition in registers.
+template <int R, int NT>
+__device__ __forceinline__ void store_rc4_tr(float* reg, uint32_t okbits, unsigned char* lds, int tid) {
+  constexpr int RQ = R / 4, KG = NT / RQ, KPT = BK / KG;
+  const int rq = tid % RQ, kg = tid / RQ;
+  if (okbits != (1u << KPT) - 1u) {      // zeroed in the registers: the row sums of the caller read them afterwards
+#pragma unroll
+    for (int e = 0; e < KPT; ++e)
+      if (!((okbits >> e) & 1u)) { reg[4 * e + 0] = 0.f; reg[4 * e + 1] = 0.f; reg[4 * e + 2] = 0.f; reg[4 * e + 3] = 0.f; }
+  }
+#pragma unroll
+  for (int e = 0; e < KPT; ++e) {
+    uint2 u;
+    u.x = pack_bf16x2(reg[4 * e + 0], reg[4 * e + 1]);
+    u.y = pack_bf16x2(reg[4 * e + 2], reg[4 * e + 3]);
+    *reinterpret_cast<uint2*>(lds + (kg * KPT + e) * tr_stride<R>() + 8 * rq) = u;
+  }
+}
+
 template <int R, int NT>
 __device__ __forceinline__ uint32_t load_rc1(float* reg, const float* __restrict__ slab, int64_t s_k, int64_t row0,
                                              int64_t rows, int64_t k0, int64_t kend, int tid, int shiftT, int shift) {
@@ -552,7 +574,9 @@ struct Stage {
   static constexpr bool IS16 = KIND == KC16 || KIND == RC16;
   static constexpr int NREG32 = IS16 ? 1 : R * BK / NT;
   static constexpr int NREG16 = IS16 ? R * 4 / NT : 1;
-  static constexpr int LDS_BYTES = KIND == RC16 ? BK * tr_stride<R>() : R * (BF16 ? 64 : 128);
+  // [k][row] image read through the transposing LDS read: 16-bit row-contiguous operands, and fp32 ones in bf16 precision
+  static constexpr bool TR = KIND == RC16 || (BF16 && VEC && KIND == RC32);
+  static constexpr int LDS_BYTES = TR ? BK * tr_stride<R>() : R * (BF16 ? 64 : 128);
   float r32[NREG32];
   uint4 r16[NREG16];
   uint32_t ok = 0;
@@ -576,6 +600,7 @@ struct Stage {
   }
   __device__ __forceinline__ void store(unsigned char* lds, int64_t kend, int tid) {
     if constexpr (KIND == KC32) store_kc<BF16, R, NT>(r32, lds, kcur, kend, tid);
+    else if constexpr (KIND == RC32 && VEC && BF16) store_rc4_tr<R, NT>(r32, ok, lds, tid);
     else if constexpr (KIND == RC32 && VEC) store_rc4<BF16, R, NT>(r32, ok, lds, tid);
     else if constexpr (KIND == RC32) store_rc1<BF16, R, NT>(r32, ok, lds, tid);
     else if constexpr (KIND == KC16) store_kc16<R, NT>(r16, lds, kcur, kend, tid);
@@ -587,10 +612,11 @@ template <bool BF16, int AK, int BKD, bool VEC, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (TN == 4 ? 2 : (BF16 ? 3 : 2)) : 1)) void gemm_kernel(GemmParams p) {
   constexpr int NT = 64 * WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int ROWB = BF16 ? 64 : 128;
-  constexpr bool A_RC = AK == RC32 || AK == RC16, A_TR = AK == RC16, B_TR = BKD == RC16;
+  constexpr bool A_RC = AK == RC32 || AK == RC16;
   static_assert(BF16 || (AK < KC16 && BKD < KC16), "16-bit operands: bf16 kernels only");
   using StA = Stage<BF16, AK, BM, NT, VEC>;
   using StB = Stage<BF16, BKD, BN, NT, VEC>;
+  constexpr bool A_TR = StA::TR, B_TR = StB::TR;
   constexpr int A_BYTES = StA::LDS_BYTES, B_BYTES = StB::LDS_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
 
