@@ -51,6 +51,19 @@ def main():
         tb = timeit(lambda: ops.rnn_bwd(cell, prec, B, T, H, bd))
         print(f"cell={cell} B={B} store={sdt}: fwd(train) {tf:.1f} us  fwd(infer) {ti:.1f} us  bwd {tb:.1f} us   "
               f"per step: {tf / T:.2f} / {ti / T:.2f} / {tb / T:.2f} us")
+        from timeautodiff_amd import _lib
+        lib = _lib.load()
+        if hasattr(lib, "tad_dbg_rnn_stamps"):          # diagnostic build (-DEXP_STAMPS) only
+            import ctypes
+            for nm, dirs_ in (("train", fd), ("infer", fi)):
+                buf = (ctypes.c_ulonglong * 8)()
+                lib.tad_dbg_rnn_stamps(None, 1)
+                ops.rnn_fwd(cell, prec, B, T, H, dirs_)
+                torch.cuda.synchronize()
+                lib.tad_dbg_rnn_stamps(buf, 0)
+                n = max(buf[7], 1)
+                names = ["seed", "mma", "xproj prefetch issue", "gate math + stores", "barrier"]
+                print(f"  fwd({nm}) cycles per step (wave 0): " + ", ".join(f"{k} {buf[i] / n:.0f}" for i, k in enumerate(names)))
 
 
 if __name__ == "__main__":

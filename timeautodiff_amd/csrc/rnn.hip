@@ -16,6 +16,20 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// Diagnostic build only (-DEXP_STAMPS): cycle counts of the phases of a forward step, summed over the steps
+// of wave 0 of every workgroup, in a buffer of their own that no kernel reads.
+#ifdef EXP_STAMPS
+__device__ unsigned long long g_rnn_stamps[8];
+#define RSTAMP(var) __builtin_amdgcn_sched_barrier(0); unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0)
+extern "C" int tad_dbg_rnn_stamps(unsigned long long* out8, int reset) {
+  if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_rnn_stamps), 64);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_rnn_stamps), z, 64); }
+  return 0;
+}
+#else
+#define RSTAMP(var)
+#endif
+
 namespace {
 
 constexpr int MAXDIR = 2;
@@ -78,6 +92,7 @@ __global__ void pack_kernel(PackArgs a) {
 // acc[n] += A(32 x K from LDS) * B(block stream): blocks ordered [kk][n], 64 uint4 each.  The first kl k-blocks
 // are read from a copy of theirs in LDS (wl, same order), the rest from global memory through a ring of PF
 // k-blocks in registers; the ring's first loads are issued before the LDS part, which hides their latency.
+// (Routing the LDS blocks through the ring as well was measured slower: the forward LSTM then spills.)
 template <bool BF16, int NT, int PF>
 __device__ __forceinline__ void mma_stream(f32x16* acc, const unsigned char* lds_a, int lds_ld,
                                            const uint4* __restrict__ wp, int nk, int lane, const uint4* wl = nullptr, int kl = 0) {
@@ -234,6 +249,7 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cr = (r & 3) + 8 * (r >> 2);
+      if (r >= rlive) { raw[r] = SL::zero(); continue; }      // no batch row in this register: nothing to fetch
       const bool ok = uok && (cr + 4 * half) < a.rpw && (b0 + cr + 4 * half) < a.B;
       const unsigned char* xp = xbase + (b0 + cr) * (int64_t)T * d.ld_xproj * SL::ESZ;
       raw[r] = ok ? *reinterpret_cast<const raw_t*>(xp + voff) : SL::zero();
@@ -261,10 +277,17 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
     if (wave < a.NJ) load_xp(0, 0, nraw);
   }
 
+#ifdef EXP_STAMPS
+  unsigned long long sSeed = 0, sMma = 0, sPre = 0, sGate = 0, sBar = 0;
+#endif
   for (int step = 0; step < T; ++step) {
     const int tt = d.reverse ? T - 1 - step : step;
     const unsigned char* cur = smem + (size_t)(step & 1) * buf_bytes;
     unsigned char* nxt = smem + (size_t)((step + 1) & 1) * buf_bytes;
+    RSTAMP(q0);
+#ifdef EXP_STAMPS
+    unsigned long long q1 = q0, q2 = q0, q3 = q0;
+#endif
 #pragma unroll
     for (int jj = 0; jj < JPW; ++jj) {
       const int j = wave + jj * nw;
@@ -280,10 +303,19 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
           load_xp(step, jj, raw);
           seed(raw, acc, xn);
         }
+#ifdef EXP_STAMPS
+        { RSTAMP(qq); q1 = qq; }
+#endif
         mma_stream<BF16, G, PF>(acc, cur, a.lds_ld, wp + (int64_t)j * a.nk * G * 64, a.nk, lane, wl, JPW == 1 ? a.kl : 0);
+#ifdef EXP_STAMPS
+        { RSTAMP(qq); q2 = qq; }
+#endif
         if constexpr (PREFETCH) {
           if (step + 1 < T) load_xp(step + 1, 0, nraw);
         }
+#ifdef EXP_STAMPS
+        { RSTAMP(qq); q3 = qq; }
+#endif
         const uint32_t ooff = (uint32_t)((4 * half * T + tt) * (int)d.ld_out + u);
         const uint32_t goff = (uint32_t)(((4 * half * T + tt) * (int)d.ld_gates + 4 * u) * SL::ESZ);
         const uint32_t coff = (uint32_t)((4 * half * T + tt) * (int)d.ld_c + u);
@@ -328,8 +360,19 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
         }
       }
     }
+    RSTAMP(q4);
     __syncthreads();
+    RSTAMP(q5);
+#ifdef EXP_STAMPS
+    sSeed += q1 - q0; sMma += q2 - q1; sPre += q3 - q2; sGate += q4 - q3; sBar += q5 - q4;
+#endif
   }
+#ifdef EXP_STAMPS
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_rnn_stamps[0], sSeed); atomicAdd(&g_rnn_stamps[1], sMma); atomicAdd(&g_rnn_stamps[2], sPre);
+    atomicAdd(&g_rnn_stamps[3], sGate); atomicAdd(&g_rnn_stamps[4], sBar); atomicAdd(&g_rnn_stamps[7], (unsigned long long)T);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
