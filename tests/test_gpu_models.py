@@ -437,3 +437,92 @@ def test_train_diffusion_on_windowed_tables_equals_stacked_tensors(dev):
     assert np.max(np.abs(np.array(runs[0][0]) - np.array(runs[1][0])) / np.abs(np.array(runs[0][0]))) < 1e-5
     for k in runs[0][1]:
         assert fu.rel_err(runs[1][1][k], runs[0][1][k]) < 1e-4, k
+
+
+# ---------------------------------------------------------------------------- model dimensions of the other workloads
+BASELINE_SHAPES = {
+    # name: (schema, denoiser H, T, batch, VAE hidden, mask)
+    "metro_T48_H512": (dict(n_bins=0, n_cats=3, n_nums=5, cards=[12, 1, 11]), 512, 48, 3, 512, "bern"),       # Metro_Traffic
+    "etth1_T96_H200": (dict(n_bins=0, n_cats=0, n_nums=7, cards=[]), 200, 96, 3, 512, "ones"),                # ETTh1 long windows
+    "airq_T48_H512": (dict(n_bins=0, n_cats=0, n_nums=13, cards=[]), 512, 48, 2, 512, "bern"),                # AirQuality, 10 % point mask
+}
+
+
+@pytest.mark.parametrize("name", list(BASELINE_SHAPES))
+def test_denoiser_at_baseline_model_dimensions_vs_oracle(dev, name):
+    """BiRNN_score at the hidden size, window length and column schema of the Metro / ETTh1 / AirQuality workloads
+    (H = 512 takes the two-chunks-per-wave and gate-by-gate forms of the sequence kernels), small batch, fp32:
+    output, loss and every parameter gradient against the oracle on the same seeded inputs, 1e-4."""
+    sd_, H, T, B, _, _ = BASELINE_SHAPES[name]
+    sch = Schema(sd_["n_bins"], sd_["n_cats"], sd_["n_nums"], list(sd_["cards"]))
+    K, E = 6, 128
+    meta = dict(K=K, H=H, E=E, seed=91)
+    m = _make_denoiser(meta, sch, dev, "fp32")
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    data = fu.make_data(sd_, N=B, T=T, K=K, seed=92, mask_kind="ones")
+    rng = np.random.default_rng(93)
+    t = np.sort(rng.random((B, T, 1), dtype=np.float32), 1)
+    i_idx = rng.integers(0, 100, B)
+    noise = rng.standard_normal((B, T, K)).astype(np.float32)
+    pred, loss, grads = _denoiser_step(m, dev, data, t, i_idx, noise)
+    _, alphas = oops.schedule(100)
+    oloss, opred, ograds = oden.loss_and_grads(sd, data["latent"], t, i_idx, noise, data["time_info"], data["cond"], sch, alphas)
+    assert fu.rel_err(pred, opred) < TOL
+    assert abs(loss - oloss) < TOL * abs(oloss)
+    errs = {k: fu.rel_err(grads[k], v.reshape(grads[k].shape)) for k, v in ograds.items()}
+    assert max(errs.values()) < TOL, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+
+
+@pytest.mark.parametrize("name", ["metro_T48_H512", "airq_T48_H512"])
+def test_vae_at_baseline_model_dimensions_vs_oracle(dev, name):
+    """DeapStack at hidden 512 / T = 48 with the Metro (cards [12, 1, 11]) and AirQuality (13 numericals) schemas and a
+    Bernoulli(0.1) int32 point mask: latents, heads, the masked mixed loss and every gradient against the oracle, fp32."""
+    sd_, _, T, B, Hv, mk = BASELINE_SHAPES[name]
+    sch = Schema(sd_["n_bins"], sd_["n_cats"], sd_["n_nums"], list(sd_["cards"]))
+    L, E, beta = 6, 128, 0.05
+    meta = dict(H=Hv, E=E, L=L, seed=95)
+    ae = _make_vae(meta, sch, dev, "fp32")
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in ae.state_dict().items()}
+    data = fu.make_data(sd_, N=B, T=T, K=L, seed=96, mask_kind=mk)
+    eps = np.random.default_rng(97).standard_normal((B, T, L)).astype(np.float32)
+    rows = B * T
+    eng = ae.engine(dev)
+    inp = T_(data["response"] + data["cond"], dev)
+    mask = T_(data["mask"], dev)
+    cond = T_(data["cond"], dev)
+    parts = torch.zeros(3 + max(sch.n_cats, 1), device=dev)
+    eng.fp.zero_grad()
+    zz, mu, lv = eng.encoder(inp, T_(eps, dev), train=True, kld_sum=parts[2 + max(sch.n_cats, 1):])
+    eng.decoder(zz, mask, cond, target=inp * mask, scales=eng.loss_scales(rows), loss_parts=parts, train=True)
+    eng.backward(beta, rows)
+    torch.cuda.synchronize()
+    p = parts.tolist()
+    total, _ = eng.total_loss(p[:2 + sch.n_cats], p[2 + max(sch.n_cats, 1)], beta, rows)
+    ototal, ores, ograds = ovae.loss_and_grads(sd, data["response"] + data["cond"], data["mask"], data["cond"], eps, np.float32(beta), sch)
+    assert fu.rel_err(zz.cpu().numpy(), ores["z"]) < TOL and fu.rel_err(mu.cpu().numpy(), ores["mu"]) < TOL
+    assert abs(total - ototal) < TOL * abs(ototal)
+    grads = {k: eng.fp.g(k).cpu().numpy() for k in eng.fp.offsets if eng.fp.offsets[k] < eng.fp.n_active}
+    errs = {k: fu.rel_err(grads[k], v.reshape(grads[k].shape)) for k, v in ograds.items()}
+    assert max(errs.values()) < TOL, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+
+
+def test_sampler_long_windows_vs_oracle(dev):
+    """Reverse diffusion on 96-step windows (the ETTh1 workload's length), H = 200: the full 100-step trajectory with
+    injected noise against the oracle's loop, incl. the double update of the last step; fp32, 1e-4."""
+    from oracle import loops as oloops
+    from timeautodiff_amd import DIFF
+    sd_ = BASELINE_SHAPES["etth1_T96_H200"][0]
+    sch = Schema(0, 0, 7, [])
+    B, T, K, H = 2, 96, 6, 200
+    m = _make_denoiser(dict(K=K, H=H, E=128, seed=98), sch, dev, "fp32")
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    data = fu.make_data(sd_, N=B, T=T, K=K, seed=99, mask_kind="ones")
+    rng = np.random.default_rng(100)
+    xT = rng.standard_normal((B, T, K)).astype(np.float32)
+    zs = rng.standard_normal((100, B, T, K)).astype(np.float32)
+    tgrid = np.tile(np.linspace(0, 1, T, dtype=np.float32).reshape(1, T, 1), (B, 1, 1))
+    x = DIFF.sample(torch.from_numpy(tgrid), B, T, K, 100, m, torch.from_numpy(data["time_info"]), torch.from_numpy(data["cond"]), None,
+                    noise=dict(x_T=torch.from_numpy(xT), z=torch.from_numpy(zs)))
+    betas, alphas = oops.schedule(100)
+    ref, _ = oloops.sample(sd, tgrid, data["time_info"], data["cond"], sch, xT, zs, betas, alphas)
+    assert fu.rel_err(x.cpu().numpy(), ref) < TOL
