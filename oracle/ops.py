@@ -33,7 +33,8 @@ _ROUND_OPERANDS = False
 # With storage rounding on as well (``with bf16_operands(storage=True):``) the per-timestep tensors of a
 # recurrent layer that the HIP path keeps in HBM as bf16 (input-side pre-activations, the gate stash read by
 # the backward, the pre-activation gradients) are rounded to bf16 where the kernels store them.  The HIP
-# path does so for a layer with an even hidden size and an input width that is a multiple of 8.
+# path does so for every layer with an even hidden size (an input width that is not a multiple of 8 is padded
+# with zero columns there, which changes no value).
 _ROUND_STORAGE = False
 
 
@@ -61,7 +62,7 @@ class bf16_operands:
 
 def rnn_store_bf16(H, in_dim):
     """True if a recurrent layer of this shape keeps its per-timestep tensors as bf16 (see above)."""
-    return _ROUND_STORAGE and H % 2 == 0 and in_dim % 8 == 0
+    return _ROUND_STORAGE and H % 2 == 0        # any input width: the kernels pad it to a multiple of 8 with zeros
 
 
 def stored(a, as_bf16):

@@ -133,9 +133,10 @@ class RnnStack:
 
     The per-timestep tensors (input-side pre-activations, gate stash, pre-activation
     gradients) are gate-interleaved: column d*4H + 4u + s holds slot s of unit u of
-    direction d.  In bf16 precision a layer whose shapes allow 16-byte chunks (H even,
-    input width a multiple of 8) keeps them, and the gate-interleaved image of W_ih, in
-    HBM as bfloat16; otherwise they are float32."""
+    direction d.  In bf16 precision a layer with an even H keeps them, and the gate-interleaved
+    image of W_ih, in HBM as bfloat16; otherwise they are float32.  The 16-byte bf16 chunks need an
+    input width that is a multiple of 8: a layer whose width is not (the VAE encoders read F = 28
+    columns) works on a zero-padded copy of its input and a zero-padded weight image.""" 
 
     IN_SLOTS = {CELL_LSTM: (0, 1, 2, 3), CELL_GRU: (0, 1, 2, -1)}     # dgates slot -> gate of W_ih / b_ih
     HID_SLOTS = {CELL_LSTM: (0, 1, 2, 3), CELL_GRU: (0, 1, -1, 2)}    # dgates slot -> gate of W_hh / b_hh
@@ -153,9 +154,8 @@ class RnnStack:
                          for _ in range(num_layers)]
         self.packed_b = [[torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.ndir)]
                          for _ in range(num_layers)]
-        self.store = [torch.bfloat16 if (prec == BF16 and H % 2 == 0 and self.in_l(layer) % 8 == 0) else torch.float32
-                      for layer in range(num_layers)]
-        self.w_gl = [torch.empty(self.ndir * 4 * H, self.in_l(layer), dtype=self.store[layer], device=dev)
+        self.store = [torch.bfloat16 if (prec == BF16 and H % 2 == 0) else torch.float32 for layer in range(num_layers)]
+        self.w_gl = [torch.empty(self.ndir * 4 * H, self.in_p(layer), dtype=self.store[layer], device=dev)
                      for layer in range(num_layers)]
         self.bias_gl = [torch.empty(self.ndir * 4 * H, dtype=torch.float32, device=dev) for _ in range(num_layers)]
         self._ver_f = self._ver_b = -1
@@ -177,6 +177,22 @@ class RnnStack:
         if layer == 0:
             return self.in_dim
         return self.ndir * self.H if self.mode == "bidir" else self.H
+
+    def in_p(self, layer):
+        """Input width the kernels see: padded to a multiple of 8 where the layer stores bf16."""
+        n = self.in_l(layer)
+        return -(-n // 8) * 8 if self.store[layer] == torch.bfloat16 else n
+
+    def _padded(self, layer, x, ws, tag):
+        """x [BT, in_l] -> [BT, in_p] with zero pad columns (x itself when no padding is needed)."""
+        n, npad = self.in_l(layer), self.in_p(layer)
+        if npad == n:
+            return x
+        key = f"{tag}.xpad{layer}"
+        fresh = key not in ws.bufs or tuple(ws.bufs[key].shape) != (x.shape[0], npad)
+        xp = ws.get(key, (x.shape[0], npad), zero=fresh)        # the pad columns are zeroed once and never written
+        xp[:, :n].copy_(x)
+        return xp
 
     def pack(self, need_bwd=True):
         """Refresh the kernel-side images of the parameters (W_hh fragments, gate-interleaved W_ih
@@ -222,10 +238,11 @@ class RnnStack:
             sdt = self.store[layer]
             xproj = ws.get(f"{tag}.xproj{layer}", (BT, nd * H4), dtype=sdt)
             if self.mode == "bidir" or layer == 0:
-                self._xproj(layer, inp, self.w_gl[layer], self.bias_gl[layer], xproj)
+                self._xproj(layer, self._padded(layer, inp, ws, tag), self.w_gl[layer], self.bias_gl[layer], xproj)
             else:
                 for d in range(nd):
                     sl = slice(d * H4, (d + 1) * H4)
+                    assert self.in_p(layer) == self.in_l(layer)        # H even: no padding between heads
                     self._xproj(layer, inp[:, d * H:(d + 1) * H], self.w_gl[layer][sl], self.bias_gl[layer][sl], xproj[:, sl])
             out = ws.get(f"{tag}.out{layer}", (BT, nd * H))
             gates = ws.get(f"{tag}.gates{layer}", (BT, nd * H4), dtype=sdt) if train else None
@@ -286,8 +303,10 @@ class RnnStack:
                                       T=T, tshift=(1 if self.rev[d] else -1), gate_map=hid_map)
             # gradient wrt the layer input (the unused slot of a GRU meets a zero row of the weight image)
             if layer > 0 or need_dx:
-                dx = ws.get(f"{tag}.dx{layer}", (BT, in_l if shared else nd * H))
+                padded = shared and self.in_p(layer) != in_l
+                dx = ws.get(f"{tag}.dx{layer}", (BT, (self.in_p(layer) if padded else in_l) if shared else nd * H))
                 ro = relu_of if layer == 0 else None
+                assert not (padded and ro is not None), "a ReLU mask on a padded layer input is not supported"
                 bwd_data = (lambda dy, w, o, r=None: ops.linear_bwd_data_b16(dy, w, o, relu_of=r)) if sdt == torch.bfloat16 else \
                     (lambda dy, w, o, r=None: ops.linear_bwd_data(prec, dy, w, o, relu_of=r))
                 if shared:
@@ -296,7 +315,7 @@ class RnnStack:
                     for d in range(nd):
                         sl = slice(d * H4, (d + 1) * H4)
                         bwd_data(dg[:, sl], self.w_gl[layer][sl], dx[:, d * H:(d + 1) * H])
-                dout = dx
+                dout = dx[:, :in_l] if padded else dx            # the pad columns meet zero weights: they hold zeros
             else:
                 dout = None
         return dout
