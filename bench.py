@@ -203,6 +203,28 @@ def main():
     roof.update(kernel=dom, avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=d["calls"] // NTR,
                 algorithmic_bytes_per_launch=round(by_l), algorithmic_flops_per_launch=round(fl_l),
                 tflops=round(fl_l / avg_s / 1e12, 2), share_of_step=round(d["ms"] / NTR / ms_step, 3))
+    # The weight-gradient products of a backward pass run on a second stream beside the main one, so the durations
+    # above are those of kernels that SHARE the chip (their sum exceeds the step time).  For the quality of the
+    # dominant kernel by itself, the same step is traced once more with every launch on one stream.
+    fp = trainer.eng.fp
+    if fp.side is not None:
+        side, fp.side = fp.side, None
+        try:
+            with ops.LaunchTrace() as tr1:
+                for _ in range(NTR):
+                    trainer.step()
+            calls1 = tr1.summary_by_kernel().get(dom, {})
+        finally:
+            fp.side = side
+        n1 = sum(c[0] for c in calls1.values())
+        ms1 = sum(c[1] for c in calls1.values())
+        if n1:
+            a1 = ms1 / n1 * 1e-3
+            roof["alone_on_the_chip"] = dict(
+                avg_launch_us=round(a1 * 1e6, 2),
+                achieved=round((by_l if hbm_bound else fl_l) / a1 / (1e9 if hbm_bound else 1e12), 2),
+                frac=round((by_l / PEAK_HBM if hbm_bound else fl_l / PEAK_BF16) / a1, 4),
+                note="same step with the gradient stream off (TAD_GRAD_STREAM=0): no other kernel runs beside it")
     kernels = {k: dict(launches_per_step=v["calls"] // NTR, ms_per_step=round(v["ms"] / NTR, 3),
                        avg_us=round(v["ms"] / v["calls"] * 1e3, 1),
                        tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),

@@ -403,6 +403,16 @@ def test_sampler_fullsize_sharding_invariance(dev):
     xa = DIFF.sample(tgrid[:h], h, T, K, 100, m, ti[:h], cond[:h], None, noise=dict(x_T=noise["x_T"][:h], z=noise["z"][:, :h]))
     assert torch.isfinite(x).all()
     assert torch.equal(x[:h], xa)
+    # the batch walks the loop in concurrent chunks on streams of their own: no value depends on how many
+    x1 = DIFF.sample(tgrid, B, T, K, 100, m, ti, cond, None, noise=noise, streams=1)
+    x3 = DIFF.sample(tgrid, B, T, K, 100, m, ti, cond, None, noise=noise, streams=3)
+    assert torch.equal(x, x1) and torch.equal(x, x3)
+    # ... nor on replaying the loop as one captured HIP graph (second call: replay of the cached graph on new noise)
+    xg = DIFF.sample(tgrid, B, T, K, 100, m, ti, cond, None, noise=noise, streams=2, graph=True)
+    assert torch.equal(x, xg)
+    noise2 = dict(x_T=noise["x_T"].flip(0), z=noise["z"].flip(1))
+    xg2 = DIFF.sample(tgrid, B, T, K, 100, m, ti.flip(0), cond.flip(0), None, noise=noise2, streams=2, graph=True)
+    assert torch.equal(xg2, x.flip(0))
 
 
 def test_train_diffusion_on_windowed_tables_equals_stacked_tensors(dev):

@@ -326,7 +326,7 @@ def train_diffusion(latent_features, cond_df, data_dict, hidden_dim, num_layers,
 # ---------------------------------------------------------------------------
 @torch.no_grad()
 def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, noise=None, dtype=None,
-           process_group=None, noise_source="reference", keep=None):
+           process_group=None, noise_source="reference", keep=None, streams=None, graph=None):
     """reference DIFF.py:333-352: x_T ~ N(0,I), then 100 reverse steps with the step-0 double
     update.  Loop-invariant work (cond path, t_enc, time_encode and their share of `proj`) is
     computed once; the per-step i_enc contribution is a precomputed [steps, H] table.
@@ -335,7 +335,10 @@ def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, 
     noise_source 'reference' (torch CPU generator in the reference's order, staged to the
     device once) or 'device'; dtype overrides the model's compute dtype; process_group shards
     the batch over ranks with no communication (each rank returns its slice); keep = dict that
-    receives x after the listed steps (keys = step numbers)."""
+    receives x after the listed steps (keys = step numbers); streams = number of contiguous chunks of
+    the batch that walk the loop concurrently on HIP streams of their own (default 2 for batches of
+    at least 512 sequences; no value depends on it); graph = True replays the loop as one
+    HIP graph captured per batch shape (first call of a shape runs it twice) instead of enqueueing it kernel by kernel."""
     if diffusion_steps != globals()["diffusion_steps"]:
         raise ValueError("the schedule tables are built for 100 diffusion steps (reference DIFF.py:93-95)")
     if dtype is not None:
@@ -366,5 +369,5 @@ def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, 
     def prep(a, last):
         return a[lo:hi].to(device=d, dtype=torch.float32).reshape(nb, T, last).contiguous()
     eng.sample_loop(x, prep(t, 1), prep(time_info, time_info.shape[-1]), prep(cond, cond.shape[-1]), z_all,
-                    betas, alphas, keep=keep)
+                    betas, alphas, keep=keep, streams=streams, graph=graph)
     return x

@@ -2,6 +2,7 @@
 the forward/backward launch sequences of the denoiser (BiRNN_score) and the VAE
 (DeapStack).  All arithmetic happens in libtad_hip.so; torch only owns the memory."""
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -10,6 +11,14 @@ from . import ops
 from .ops import ACT_RELU, BF16, CELL_GRU, CELL_LSTM, F32
 
 ALIGN = 64  # floats (256 B)
+# TAD_GRAD_STREAM=0 keeps every launch of a backward pass on one stream (experiments, per-kernel timing in isolation)
+GRAD_STREAM = os.environ.get("TAD_GRAD_STREAM", "1") != "0"
+# chunks of the sampling batch that walk the reverse loop concurrently (1 = the whole batch on the current stream)
+SAMPLE_STREAMS = int(os.environ.get("TAD_SAMPLE_STREAMS", "2"))
+# TAD_SAMPLE_GRAPH=1: replay the reverse loop as one captured HIP graph per batch shape instead of enqueueing it kernel
+# by kernel (off by default: at 1k sequences the loop is device-bound and the graph measured no faster)
+SAMPLE_GRAPH = os.environ.get("TAD_SAMPLE_GRAPH", "0") == "1"
+GRAD_IMMEDIATE = os.environ.get("TAD_GRAD_STREAM", "1") == "1"
 
 
 def prec_of(dtype):
@@ -58,6 +67,14 @@ class FlatParams:
         self.step = 0
         self.shapes = {n: tuple(p.shape) for n, p in params.items()}
         self.version = 0          # bumped whenever parameter values change
+        # weight-gradient products are off the critical path of a backward pass (nothing downstream reads them
+        # before the optimizer step): they go to a second HIP stream and fill the compute units that the
+        # latency-bound sequence kernels of the main stream leave idle
+        self.side = torch.cuda.Stream(device=device) if (GRAD_STREAM and torch.device(device).type == "cuda") else None
+        self._fork_ev = torch.cuda.Event() if self.side is not None else None
+        self._join_ev = torch.cuda.Event() if self.side is not None else None
+        self._side_busy = False
+        self._queued = []
         for name, p in params.items():
             view = self.p(name)
             view.copy_(p.data.to(device=device, dtype=torch.float32))
@@ -95,6 +112,37 @@ class FlatParams:
 
     def zero_grad(self):
         self.gflat[:self.n_active].zero_()
+
+    def defer(self, fn, *args, **kwargs):
+        """Queue a launch whose only result is an accumulation into the gradient buffer.  It is issued on the
+        side stream at the next ``release()`` (ordered after everything enqueued on the current stream by then).
+        ``join()`` must precede any reader of the gradients and any writer of the launch's operands."""
+        if self.side is None:
+            return fn(*args, **kwargs)
+        self._queued.append((fn, args, kwargs))
+        if GRAD_IMMEDIATE:
+            self.release()
+
+    def release(self):
+        """Issue the queued launches on the side stream; called right before a latency-bound kernel goes to the
+        current stream, so that the two run side by side."""
+        if not self._queued:
+            return
+        self._fork_ev.record()
+        self.side.wait_event(self._fork_ev)
+        with torch.cuda.stream(self.side):
+            for fn, args, kwargs in self._queued:
+                fn(*args, **kwargs)
+        self._queued.clear()
+        self._side_busy = True
+
+    def join(self):
+        """Issue what is still queued; the current stream then waits for everything deferred so far."""
+        self.release()
+        if self._side_busy:
+            self._join_ev.record(self.side)
+            torch.cuda.current_stream().wait_event(self._join_ev)
+            self._side_busy = False
 
     def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.step += 1
@@ -258,6 +306,26 @@ class RnnStack:
             inp = out
         return inp
 
+    def _weight_grads(self, layer, dg, inp, out, gb_ih, gb_hh, in_map, hid_map):
+        """Weight and bias gradients of one layer from its pre-activation gradients ``dg``."""
+        fp, H, nd, prec, T = self.fp, self.H, self.ndir, self.prec, self._T
+        GH, H4 = self.G * H, 4 * H
+        lstm = self.cell == CELL_LSTM
+        if self.mode == "bidir" or layer == 0:
+            ops.linear_bwd_weight(prec, dg, inp, fp.ggroup(self.name("weight_ih", layer, 0), nd * GH, self.in_l(layer)),
+                                  db=gb_ih, db2=gb_hh if lstm else None, gate_map=in_map)
+        else:
+            for d in range(nd):
+                sl = slice(d * GH, (d + 1) * GH)
+                ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], inp[:, d * H:(d + 1) * H],
+                                      fp.g(self.name("weight_ih", layer, d)), db=gb_ih[sl], db2=gb_hh[sl] if lstm else None,
+                                      gate_map=in_map)
+        # recurrent weights: dW_hh += dgates^T h_{t-1}
+        for d in range(nd):
+            ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], out[:, d * H:(d + 1) * H],
+                                  fp.g(self.name("weight_hh", layer, d)), db=None if lstm else gb_hh[d * GH:(d + 1) * GH],
+                                  T=T, tshift=(1 if self.rev[d] else -1), gate_map=hid_map)
+
     def backward(self, dout, ws: Workspace, tag, need_dx, relu_of=None):
         fp, H, G, nd, prec = self.fp, self.H, self.G, self.ndir, self.prec
         B, T = self._B, self._T
@@ -280,6 +348,7 @@ class RnnStack:
                                  cstate=cst[:, d * H:(d + 1) * H] if lstm else None,
                                  out=out[:, d * H:(d + 1) * H] if not lstm else None,
                                  w_packed_t=self.packed_b[layer][d], dgates=dg[:, sl], reverse=self.rev[d]))
+            fp.release()
             ops.rnn_bwd(self.cell, prec, B, T, H, dirs)
             shared = self.mode == "bidir" or layer == 0
             in_l = self.in_l(layer)
@@ -287,20 +356,7 @@ class RnnStack:
             # LSTM b_ih and b_hh both receive the sums; GRU b_hh receives the hidden-side sums with the W_hh pass
             gb_ih = fp.ggroup(self.name("bias_ih", layer, 0), 1, nd * GH).view(-1)
             gb_hh = fp.ggroup(self.name("bias_hh", layer, 0), 1, nd * GH).view(-1)
-            if shared:
-                ops.linear_bwd_weight(prec, dg, inp, fp.ggroup(self.name("weight_ih", layer, 0), nd * GH, in_l),
-                                      db=gb_ih, db2=gb_hh if lstm else None, gate_map=in_map)
-            else:
-                for d in range(nd):
-                    sl = slice(d * GH, (d + 1) * GH)
-                    ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], inp[:, d * H:(d + 1) * H],
-                                          fp.g(self.name("weight_ih", layer, d)), db=gb_ih[sl], db2=gb_hh[sl] if lstm else None,
-                                          gate_map=in_map)
-            # recurrent weights: dW_hh += dgates^T h_{t-1}
-            for d in range(nd):
-                ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], out[:, d * H:(d + 1) * H],
-                                      fp.g(self.name("weight_hh", layer, d)), db=None if lstm else gb_hh[d * GH:(d + 1) * GH],
-                                      T=T, tshift=(1 if self.rev[d] else -1), gate_map=hid_map)
+            fp.defer(self._weight_grads, layer, dg, inp, out, gb_ih, gb_hh, in_map, hid_map)
             # gradient wrt the layer input (the unused slot of a GRU meets a zero row of the weight image)
             if layer > 0 or need_dx:
                 padded = shared and self.in_p(layer) != in_l
@@ -376,10 +432,10 @@ class EmbBlock:
         a2 = ws.get(f"{tag}.a2", (rows, E))
         da2 = ws.get(f"{tag}.da2", (rows, E))
         ops.linear_bwd_data(prec, dout, fp.p(pre + "mlp_output.2.weight"), da2, relu_of=a2)
-        ops.linear_bwd_weight(prec, dout, a2, fp.g(pre + "mlp_output.2.weight"), db=fp.g(pre + "mlp_output.2.bias"))
+        fp.defer(ops.linear_bwd_weight, prec, dout, a2, fp.g(pre + "mlp_output.2.weight"), db=fp.g(pre + "mlp_output.2.bias"))
         decat = ws.get(f"{tag}.decat", (rows, self.cat_dim))
         ops.linear_bwd_data(prec, da2, fp.p(pre + "mlp_output.0.weight"), decat)
-        ops.linear_bwd_weight(prec, da2, ecat, fp.g(pre + "mlp_output.0.weight"), db=fp.g(pre + "mlp_output.0.bias"))
+        fp.defer(ops.linear_bwd_weight, prec, da2, ecat, fp.g(pre + "mlp_output.0.weight"), db=fp.g(pre + "mlp_output.0.bias"))
         if nd:
             gt = fp.ggroup(f"{pre}embeddings_list.0.weight", sum(self.cards), E)
             ops.embed_bwd(x[:, :nd], decat[:, :nd * E], gt, self.tab_off, self.cards, E)
@@ -390,17 +446,18 @@ class EmbBlock:
             dy1 = decat[:, nd * E:]
             da1 = ws.get(f"{tag}.da1", (rows, 16 * nn))
             ops.linear_bwd_data(prec, dy1, fp.p(pre + "mlp_nums.2.weight"), da1)
-            ops.linear_bwd_weight(prec, dy1, a1, fp.g(pre + "mlp_nums.2.weight"), db=fp.g(pre + "mlp_nums.2.bias"))
+            fp.defer(ops.linear_bwd_weight, prec, dy1, a1, fp.g(pre + "mlp_nums.2.weight"), db=fp.g(pre + "mlp_nums.2.bias"))
             dz1 = ws.get(f"{tag}.dz1", (rows, 16 * nn))
             ops.silu_bwd(z1, da1, dz1)
-            ops.linear_bwd_weight(prec, dz1, feats, fp.g(pre + "mlp_nums.0.weight"), db=fp.g(pre + "mlp_nums.0.bias"))
+            fp.defer(ops.linear_bwd_weight, prec, dz1, feats, fp.g(pre + "mlp_nums.0.weight"), db=fp.g(pre + "mlp_nums.0.bias"))
 
 
-def _lin_bwd(prec, dy, x, w, gw, gb, dx=None, relu_of=None, accumulate=False):
-    """Backward of y = x W^T + b: weight/bias grads always, input grad if dx is given."""
+def _lin_bwd(fp, prec, dy, x, w, gw, gb, dx=None, relu_of=None, accumulate=False):
+    """Backward of y = x W^T + b: weight/bias grads always (deferred to the gradient stream of ``fp``), input grad
+    if dx is given."""
     if dx is not None:
         ops.linear_bwd_data(prec, dy, w, dx, relu_of=relu_of, accumulate=accumulate)
-    ops.linear_bwd_weight(prec, dy, x, gw, db=gb)
+    fp.defer(ops.linear_bwd_weight, prec, dy, x, gw, db=gb)
 
 
 # ---------------------------------------------------------------------------
@@ -438,6 +495,8 @@ class DenoiserEngine:
         self.scale_i = module.i_enc.scale.to(device=device, dtype=torch.float32).contiguous()
         self.shift_i = module.i_enc.shift.to(device=device, dtype=torch.float32).contiguous()
         self.i_max = float(module.i_enc.max_value)
+        self._chunks = []           # (stream, workspace, event) per concurrent sampler chunk
+        self._graphs = {}           # (batch shape, chunking) -> (captured reverse loop, its static input buffers)
 
     # -- forward ------------------------------------------------------------
     def forward(self, x, t, i_f, time_info, cond, train=False):
@@ -498,40 +557,127 @@ class DenoiserEngine:
         lout = ws.get("lstm.out%d" % (self.L - 1), (BT, 2 * H))
         gout = ws.get("gru.out%d" % (self.L - 1), (BT, 2 * H))
         dln = ws.get("dln", (BT, 2 * H))
-        _lin_bwd(prec, dpred, ln, fp.p("fc.weight"), fp.g("fc.weight"), fp.g("fc.bias"), dx=dln)
+        _lin_bwd(fp, prec, dpred, ln, fp.p("fc.weight"), fp.g("fc.weight"), fp.g("fc.bias"), dx=dln)
         dlout = ws.get("dlout", (BT, 2 * H))
         ops.layernorm_bwd(dln, lout, fp.p("layer_norm.weight"), mr, dlout, fp.g("layer_norm.weight"), fp.g("layer_norm.bias"))
         dpz = self.lstm.backward(dlout, ws, "lstm", need_dx=True, relu_of=pa)      # includes the ReLU of proj
         dcat = ws.get("dcat", (BT, 4 * H))
-        _lin_bwd(prec, dpz, cat, fp.p("proj.net.0.weight"), fp.g("proj.net.0.weight"), fp.g("proj.net.0.bias"), dx=dcat)
+        _lin_bwd(fp, prec, dpz, cat, fp.p("proj.net.0.weight"), fp.g("proj.net.0.weight"), fp.g("proj.net.0.bias"), dx=dcat)
         dxh = dcat[:, :H]
-        _lin_bwd(prec, dxh, x2, None, fp.g("input_proj.net.0.weight"), fp.g("input_proj.net.0.bias"))
+        _lin_bwd(fp, prec, dxh, x2, None, fp.g("input_proj.net.0.weight"), fp.g("input_proj.net.0.bias"))
         ops.colsum(dcat[:, H:H + Lh], out_sum=fp.g("t_enc.linear_proj.bias"), row_scale=t1, scale_mul=1.0,
                    out_wsum=fp.g("t_enc.linear_proj.weight"))
         ops.colsum(dcat[:, 2 * H:2 * H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
                    out_wsum=fp.g("i_enc.linear_proj.weight"))
         dtenc = dcat[:, 3 * H:]
         dta = ws.get("dta", (BT, H))
-        _lin_bwd(prec, dtenc, ta, fp.p("time_encode.2.weight"), fp.g("time_encode.2.weight"), fp.g("time_encode.2.bias"),
+        _lin_bwd(fp, prec, dtenc, ta, fp.p("time_encode.2.weight"), fp.g("time_encode.2.weight"), fp.g("time_encode.2.bias"),
                  dx=dta, relu_of=ta)
-        _lin_bwd(prec, dta, ti2, None, fp.g("time_encode.0.weight"), fp.g("time_encode.0.bias"))
+        _lin_bwd(fp, prec, dta, ti2, None, fp.g("time_encode.0.weight"), fp.g("time_encode.0.bias"))
         dgout = ws.get("dgout", (BT, 2 * H))
-        _lin_bwd(prec, dxh, gout, fp.p("cond_output.weight"), fp.g("cond_output.weight"), fp.g("cond_output.bias"), dx=dgout)
+        _lin_bwd(fp, prec, dxh, gout, fp.p("cond_output.weight"), fp.g("cond_output.weight"), fp.g("cond_output.bias"), dx=dgout)
         demb = self.gru.backward(dgout, ws, "gru", need_dx=True)
         self.emb.backward(demb, ws, "emb")
+        fp.join()
 
     # -- reverse diffusion --------------------------------------------------
-    def sample_loop(self, x, t, time_info, cond, z_all, betas, alphas, keep=None):
+    def sample_loop(self, x, t, time_info, cond, z_all, betas, alphas, keep=None, streams=None, graph=None):
         """The reverse-diffusion loop of reference DIFF.py:340-351, in place on x [B,T,K].
         z_all[s] is the noise of step s.  Everything that does not depend on x or on the
         step (cond path, t_enc, time_encode and their share of `proj`) is evaluated once;
-        i_enc's share of `proj` is a [steps, H] table used as a per-step bias."""
-        fp, ws, prec, H, K = self.fp, self.ws, self.prec, self.H, self.K
-        B, T, _ = x.shape
-        BT = B * T
+        i_enc's share of `proj` is a [steps, H] table used as a per-step bias.
+
+        Sequences are independent, and at sampling batch sizes the sequence kernels are bound by the latency of
+        their step-to-step chain, not by throughput: the batch is therefore cut into ``streams`` contiguous chunks
+        (default SAMPLE_STREAMS, chunks of at least 256 sequences) that walk the loop on HIP streams of their own,
+        so that one chunk's sequence kernel runs beside another chunk's matrix products.  A row's result does not
+        depend on the rows it is computed with, so the chunking changes no value."""
+        B, T, K = x.shape
         S = z_all.shape[0]
         self.lstm.pack_fwd_only()
         self.gru.pack_fwd_only()
+        b32, a32 = betas.float().cpu(), alphas.float().cpu()
+        coef = ((1 / (1 - b32).sqrt()).tolist(), (b32 / (1 - a32).sqrt()).tolist(), b32.sqrt().tolist())
+        nch = SAMPLE_STREAMS if streams is None else int(streams)
+        nch = max(1, min(nch, B // 256))
+        if keep is not None:
+            st = self._sample_setup(x, t, time_info, cond, z_all, self.ws)
+            for s in range(S - 1, -1, -1):
+                self._sample_step(st, s, coef)
+                if s in keep:
+                    keep[s] = x.clone()
+            return x
+        use_graph = (SAMPLE_GRAPH if graph is None else bool(graph)) and ops.tracing() is None
+        if not use_graph:
+            while len(self._chunks) < nch:
+                self._chunks.append(self._new_chunk())
+            chunks = self._chunks[:nch] if nch > 1 else [(None, self.ws, None)]
+            self._sample_run(x, t, time_info, cond, z_all, coef, chunks)
+            return x
+        # the whole loop (nch chunks x S steps x 8 launches) as ONE HIP graph per (batch shape, chunking): the host
+        # enqueues a single graph launch instead of thousands of kernels (for callers whose host thread is busy).
+        # A graph holds the addresses of everything it touches: its inputs are copied into buffers of its own and
+        # its chunks work in workspaces of their own, which nothing else resizes.
+        key = (B, T, K, S, nch, self.prec, tuple(time_info.shape), tuple(cond.shape))
+        ent = self._graphs.get(key)
+        args = dict(x=x, t=t, time_info=time_info, cond=cond, z=z_all)
+        if ent is None:
+            static = {k: torch.empty_like(v) for k, v in args.items()}
+            for k, v in args.items():
+                static[k].copy_(v)
+            chunks = [self._new_chunk() for _ in range(nch)] if nch > 1 else [(None, Workspace(self.device), None)]
+            run = lambda: self._sample_run(static["x"], static["t"], static["time_info"], static["cond"], static["z"],  # noqa: E731
+                                           coef, chunks)
+            run()                               # sizes the workspaces (and loads the code objects) outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            ent = self._graphs[key] = (g, static, chunks)
+        g, static, _ = ent
+        for k, v in args.items():
+            static[k].copy_(v)
+        g.replay()
+        x.copy_(static["x"])
+        return x
+
+    def _new_chunk(self):
+        return torch.cuda.Stream(device=self.device), Workspace(self.device), torch.cuda.Event()
+
+    def _sample_run(self, x, t, time_info, cond, z_all, coef, chunks):
+        """Enqueue the reverse loop for x [B,T,K] (in place): one chunk (stream, workspace, event) per contiguous
+        share of the batch, forked from and joined to the current stream; a single chunk runs on the current stream."""
+        B = x.shape[0]
+        S = z_all.shape[0]
+        nch = len(chunks)
+        if nch == 1:
+            st = self._sample_setup(x, t, time_info, cond, z_all, chunks[0][1])
+            for s in range(S - 1, -1, -1):
+                self._sample_step(st, s, coef)
+            return
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        states = []
+        for c, (stream, ws, _) in enumerate(chunks):
+            lo, hi = (B * c) // nch, (B * (c + 1)) // nch
+            stream.wait_event(fork)
+            with torch.cuda.stream(stream):
+                states.append(self._sample_setup(x[lo:hi], t[lo:hi], time_info[lo:hi], cond[lo:hi], z_all[:, lo:hi], ws))
+        for s in range(S - 1, -1, -1):
+            for c in range(nch):
+                with torch.cuda.stream(chunks[c][0]):
+                    self._sample_step(states[c], s, coef)
+        for stream, _, done in chunks:
+            done.record(stream)
+            main.wait_event(done)
+
+    def _sample_setup(self, x, t, time_info, cond, z_all, ws):
+        """Step-invariant part of the sampler for the sequences x [B,T,K] (a contiguous view), on the current stream."""
+        fp, prec, H, K = self.fp, self.prec, self.H, self.K
+        B, T, _ = x.shape
+        BT = B * T
+        S = z_all.shape[0]
         x2 = x.view(BT, K)
         cat = ws.get("s.cat", (BT, 4 * H))
         emb = self.emb.forward(cond.reshape(BT, self.F), ws, "emb")
@@ -547,30 +693,26 @@ class DenoiserEngine:
         pinv = ws.get("s.pinv", (BT, H))
         wp = fp.p("proj.net.0.weight")
         ops.linear_fwd(prec, cat, wp, fp.p("proj.net.0.bias"), pinv)
-        steps_f = torch.arange(S, device=self.device, dtype=torch.float32)
+        steps_f = ws.get("s.steps", (S,))
+        torch.arange(S, out=steps_f)
         ie = ws.get("s.ie", (S, H))
         ops.posenc_fwd(steps_f, 1, S, H, 1.0 / self.i_max, fp.p("i_enc.linear_proj.weight"), fp.p("i_enc.linear_proj.bias"),
                        self.scale_i, self.shift_i, ie)
         V = ws.get("s.V", (S, H))
         ops.linear_fwd(prec, ie, wp[:, 2 * H:3 * H], None, V)
-        xh = ws.get("s.xh", (BT, H))
-        pa = ws.get("pa", (BT, H))
-        ln = ws.get("ln", (BT, 2 * H))
-        pred = ws.get("pred", (BT, K))
-        b32, a32 = betas.float().cpu(), alphas.float().cpu()
-        c1 = (1 / (1 - b32).sqrt()).tolist()
-        c2 = (b32 / (1 - a32).sqrt()).tolist()
-        c3 = b32.sqrt().tolist()
-        for s in range(S - 1, -1, -1):
-            ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
-            ops.linear_fwd(prec, xh, wp[:, :H], V[s], pa, act=ACT_RELU, residual=pinv)
-            lout = self.lstm.forward(pa, B, T, ws, "lstm", False)
-            ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, None)
-            ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
-            ops.sampler_update(x2, pred, z_all[s], c1[s], c2[s], c3[s], s == 0)
-            if keep is not None and s in keep:
-                keep[s] = x.clone()
-        return x
+        return dict(x2=x2, B=B, T=T, ws=ws, pinv=pinv, V=V, wp=wp, z=z_all, xh=ws.get("s.xh", (BT, H)), pa=ws.get("pa", (BT, H)),
+                    ln=ws.get("ln", (BT, 2 * H)), pred=ws.get("pred", (BT, K)))
+
+    def _sample_step(self, st, s, coef):
+        """Reverse step s for the sequences of one ``_sample_setup`` state, on the current stream."""
+        fp, prec, H = self.fp, self.prec, self.H
+        x2, xh, pa, ln, pred = st["x2"], st["xh"], st["pa"], st["ln"], st["pred"]
+        ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
+        ops.linear_fwd(prec, xh, st["wp"][:, :H], st["V"][s], pa, act=ACT_RELU, residual=st["pinv"])
+        lout = self.lstm.forward(pa, st["B"], st["T"], st["ws"], "lstm", False)
+        ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, None)
+        ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
+        ops.sampler_update(x2, pred, st["z"][s], coef[0][s], coef[1][s], coef[2][s], s == 0)
 
     # -- get_loss + backward ------------------------------------------------
     def loss_and_grads(self, x0, t, i_idx, noise, time_info, cond, alphas, loss_sum, global_numel=None):
@@ -719,23 +861,24 @@ class VAEEngine:
         mu = ws.get("mu", (BT, Lt))
         lv = ws.get("lv", (BT, Lt))
         dlat = ws.get("dlat", (BT, H))
-        _lin_bwd(prec, dheads, lat, fp.pgroup(self.head_w0, self.NH, H), fp.ggroup(self.head_w0, self.NH, H),
+        _lin_bwd(fp, prec, dheads, lat, fp.pgroup(self.head_w0, self.NH, H), fp.ggroup(self.head_w0, self.NH, H),
                  fp.ggroup(self.head_b0, 1, self.NH), dx=dlat)
         if ce is not None:
             dce = ws.get("dce", (BT, self.F))
-            _lin_bwd(prec, dlat, ce, fp.p("Emb_hidden_decoder.weight"), fp.g("Emb_hidden_decoder.weight"),
+            _lin_bwd(fp, prec, dlat, ce, fp.p("Emb_hidden_decoder.weight"), fp.g("Emb_hidden_decoder.weight"),
                      fp.g("Emb_hidden_decoder.bias"), dx=dce)
             self.emb_dec.backward(dce, ws, "embdec")
         dd1 = ws.get("dd1", (BT, H))
-        _lin_bwd(prec, dlat, d1, fp.p("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.bias"),
+        _lin_bwd(fp, prec, dlat, d1, fp.p("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.bias"),
                  dx=dd1, relu_of=d1)
         dz = ws.get("dz", (BT, Lt))
-        _lin_bwd(prec, dd1, z2, fp.p("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.bias"), dx=dz)
+        _lin_bwd(fp, prec, dd1, z2, fp.p("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.bias"), dx=dz)
         dmu = ws.get("dmu", (BT, Lt))
         dlv = ws.get("dlv", (BT, Lt))
         ops.vae_reparam_bwd(dz, mu, lv, eps2, beta / (global_rows * Lt), dmu, dlv)
         dhh = ws.get("dhh", (BT, 2 * H))
-        _lin_bwd(prec, dmu, hh[:, :H], fp.p("fc_mu.weight"), fp.g("fc_mu.weight"), fp.g("fc_mu.bias"), dx=dhh[:, :H])
-        _lin_bwd(prec, dlv, hh[:, H:], fp.p("fc_logvar.weight"), fp.g("fc_logvar.weight"), fp.g("fc_logvar.bias"), dx=dhh[:, H:])
+        _lin_bwd(fp, prec, dmu, hh[:, :H], fp.p("fc_mu.weight"), fp.g("fc_mu.weight"), fp.g("fc_mu.bias"), dx=dhh[:, :H])
+        _lin_bwd(fp, prec, dlv, hh[:, H:], fp.p("fc_logvar.weight"), fp.g("fc_logvar.weight"), fp.g("fc_logvar.bias"), dx=dhh[:, H:])
         de = self.enc.backward(dhh, ws, "enc", need_dx=True)
         self.emb.backward(de, ws, "emb")
+        fp.join()

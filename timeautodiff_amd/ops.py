@@ -93,6 +93,11 @@ class LaunchTrace:
 _TRACE = None
 
 
+def tracing():
+    """The installed LaunchTrace, or None."""
+    return _TRACE
+
+
 def _call(name, *args, cost=(0.0, 0.0)):
     """Calls a C-ABI entry point.  ``cost`` = (algorithmic FLOPs, algorithmic HBM bytes: every operand and result
     once at its storage width) of the call, recorded by an installed LaunchTrace."""
