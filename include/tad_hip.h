@@ -272,6 +272,27 @@ int tad_heads_to_tensor(int64_t rows, int nb, int nc, int nn, const int32_t* car
 int tad_vae_prepare(int64_t n, const float* resp, const float* cond, const float* mask, float* inp, float* target,
                     tad_stream_t stream);
 
+/* ------------------------------------------------------------------ TV-MCG metadata corruption
+ * add_continuous_metadata_noise_subset (dataprovider_pypots.py:149-180) on cond [rows = B*T, F]:
+ * out = cond, except out[r, cols[j]] = cond[r, cols[j]] + noise[r*n_cols + j] * (level * (std_j + 1e-8)),
+ * std_j = unbiased standard deviation of column cols[j] over all rows (float64 two-pass reduction rounded
+ * to float32).  cols is a HOST array of n_cols (<= 64) distinct column indices; noise [rows, n_cols] holds
+ * the standard-normal draws (the reference's randn_like(x_cont)); stats is device scratch of 2*n_cols
+ * doubles owned by the caller (sums, then sums of squared deviations; cleared by the call).  The reference's
+ * early return for level <= 0 or no columns is the caller's. */
+int tad_metadata_noise(int64_t rows, int64_t F, int n_cols, const int32_t* cols, const float* cond, int64_t ld,
+                       const float* noise, float level, double* stats, float* out, int64_t ldo, tad_stream_t stream);
+
+/* flip_categorical_metadata_subset (dataprovider_pypots.py:182-229): out = cond, except for the n_cols
+ * (<= 64, HOST arrays cols / classes, classes[j] >= 2) selected columns, where
+ * code = (int64) cond[r, col] (truncation, as .long()), and
+ * out[r, col] = rnd[j*rows + r] < p ? base + (base >= code) : code, base = base_draw[j*rows + r]
+ * (the reference's rand_like and randint(0, classes-1) draws of that column, [n_cols, rows] each).
+ * Columns with fewer than 2 classes are skipped by the caller, as the reference skips them. */
+int tad_flip_categories(int64_t rows, int64_t F, int n_cols, const int32_t* cols, const int32_t* classes,
+                        const float* cond, int64_t ld, const float* rnd, const int64_t* base_draw, float p, float* out,
+                        int64_t ldo, tad_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -319,6 +319,38 @@ def windows_case(ref, name, rows, F, seq_len, stride, B, seed):
     print(name, tuple(stacked.shape))
 
 
+def tvmcg_case(ref, name, B, T, F, cont_idx, cat_idx, classes, level, p, seed):
+    """The TV-MCG corruption helpers (dataprovider_pypots.py:149-229) run by the reference on a seeded cond tensor,
+    with the draws they took from torch's CPU generator (replayed from the same seed in the same order)."""
+    import torch
+    sys.path.insert(0, ref)
+    import dataprovider_pypots as dpp
+    rng = np.random.default_rng(seed)
+    cond = rng.standard_normal((B, T, F)).astype(np.float32) * rng.uniform(0.5, 20, F).astype(np.float32) + 3
+    for c in cat_idx:
+        cond[:, :, c] = rng.integers(0, max(classes[c], 1), (B, T)).astype(np.float32)
+    ct = torch.from_numpy(cond)
+    torch.manual_seed(seed)
+    noisy = dpp.add_continuous_metadata_noise_subset(ct, list(cont_idx), level)
+    torch.manual_seed(seed)
+    noise = torch.randn(B, T, len(cont_idx))
+    torch.manual_seed(seed + 1)
+    flipped = dpp.flip_categorical_metadata_subset(ct, list(cat_idx), p, dict(classes))
+    torch.manual_seed(seed + 1)
+    rand, base = [], []
+    for c in cat_idx:
+        if classes[c] <= 1:
+            continue
+        rand.append(torch.rand(B, T))
+        base.append(torch.randint(0, classes[c] - 1, (B, T)))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), cond=cond, noisy=noisy.numpy(), noise=noise.numpy(),
+                        flipped=flipped.numpy(), rand=np.stack([r.numpy() for r in rand]) if rand else np.zeros((0, B, T), np.float32),
+                        base=np.stack([b.numpy() for b in base]) if base else np.zeros((0, B, T), np.int64),
+                        meta=fu.pack_meta(dict(B=B, T=T, F=F, cont_idx=list(cont_idx), cat_idx=list(cat_idx),
+                                               classes={str(k): v for k, v in classes.items()}, level=level, p=p, seed=seed)))
+    print(name, float((noisy - ct).abs().max()), int((flipped != ct).sum()))
+
+
 def schedule_case(DIFF):
     np.savez_compressed(os.path.join(HERE, "schedule.npz"), betas=DIFF.betas.numpy(), alphas=DIFF.alphas.numpy())
 
@@ -326,7 +358,7 @@ def schedule_case(DIFF):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'convert' / 'windows': write only those fixtures")
+    ap.add_argument("--only", default="", help="'convert' / 'windows' / 'tvmcg': write only those fixtures (and the ones listed before them)")
     a = ap.parse_args()
     DIFF, VAE = import_reference(a.ref)
     import torch
@@ -336,6 +368,10 @@ def main():
     windows_case(a.ref, "windows_stride12", rows=131, F=13, seq_len=48, stride=12, B=5, seed=72)
     windows_case(a.ref, "windows_exact", rows=24, F=3, seq_len=24, stride=5, B=1, seed=73)
     if a.only == "windows":
+        return
+    tvmcg_case(a.ref, "tvmcg_mixed", B=7, T=24, F=9, cont_idx=[3, 5, 6], cat_idx=[2, 4], classes={2: 5, 4: 2}, level=0.2, p=0.4, seed=81)
+    tvmcg_case(a.ref, "tvmcg_skip", B=4, T=12, F=6, cont_idx=[0], cat_idx=[1, 5, 3], classes={1: 1, 5: 12, 3: 3}, level=0.4, p=0.1, seed=82)
+    if a.only == "tvmcg":
         return
     convert_case(a.ref, "convert_mixed", S["mixed"], B=6, T=8, seed=61)
     convert_case(a.ref, "convert_metro", S["metro"], B=5, T=6, seed=62)

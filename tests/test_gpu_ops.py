@@ -722,6 +722,71 @@ def test_gather_windows_fullsize_vs_oracle(ops, dev):
         dpp.WindowedTable(D(table[:5], dev), T, 1)           # fewer rows than one window: the reference's stack([]) error
 
 
+# ---------------------------------------------------------------------------- TV-MCG metadata corruption
+@pytest.mark.parametrize("name", ["tvmcg_mixed", "tvmcg_skip"])
+def test_tvmcg_corruption_vs_reference_golden(ops, dev, name):
+    """tad_metadata_noise / tad_flip_categories through the reference-signature wrappers, on the draws the reference
+    took.  Flipped codes and untouched columns: bit-exact.  Noisy columns: 1e-6 relative (the column standard
+    deviation is a float64 reduction rounded to float32; summation order may move its last bit)."""
+    from timeautodiff_amd import dataprovider_pypots as dpp
+    z, meta = fu.load(name)
+    classes = {int(k): v for k, v in meta["classes"].items()}
+    cond = D(z["cond"], dev)
+    noisy = dpp.add_continuous_metadata_noise_subset(cond, meta["cont_idx"], meta["level"], noise=torch.from_numpy(z["noise"]))
+    got = noisy.cpu().numpy()
+    np.testing.assert_allclose(got, z["noisy"], rtol=1e-6, atol=1e-6)
+    untouched = [c for c in range(meta["F"]) if c not in meta["cont_idx"]]
+    assert np.array_equal(got[:, :, untouched], z["cond"][:, :, untouched])
+    flipped = dpp.flip_categorical_metadata_subset(cond, meta["cat_idx"], meta["p"], classes, rand=list(torch.from_numpy(z["rand"])),
+                                                   base=list(torch.from_numpy(z["base"])))
+    assert np.array_equal(flipped.cpu().numpy(), z["flipped"])
+    # the reference's early returns hand back the argument itself
+    assert dpp.add_continuous_metadata_noise_subset(cond, meta["cont_idx"], 0.0) is cond
+    assert dpp.add_continuous_metadata_noise_subset(cond, [], 0.3) is cond
+    assert dpp.flip_categorical_metadata_subset(cond, meta["cat_idx"], 0.0, classes) is cond
+    assert dpp.flip_categorical_metadata_subset(cond, [], 0.5, classes) is cond
+    with pytest.raises(KeyError):
+        dpp.flip_categorical_metadata_subset(cond, [0], 0.5, {})
+
+
+def test_tvmcg_corruption_fullsize_vs_oracle(ops, dev):
+    """Bench-sized cond (4096 x 24 x 28): oracle parity on injected draws, and the properties of device-drawn
+    corruption: only the listed columns change, flipped codes are always another valid class, the flip rate is p,
+    the added noise has level * std per column."""
+    from oracle import tvmcg as otv
+    from timeautodiff_amd import dataprovider_pypots as dpp
+    rng = np.random.default_rng(17)
+    B, T, F = 4096, 24, 28
+    cond = rng.standard_normal((B, T, F)).astype(np.float32) * rng.uniform(0.1, 30, F).astype(np.float32) + 5
+    cat_idx, classes = [0, 9], {0: 8, 9: 2}
+    for c in cat_idx:
+        cond[:, :, c] = rng.integers(0, classes[c], (B, T)).astype(np.float32)
+    cont_idx = [3, 4, 27, 11]
+    noise = rng.standard_normal((B, T, len(cont_idx))).astype(np.float32)
+    cd = D(cond, dev)
+    got = dpp.add_continuous_metadata_noise_subset(cd, cont_idx, 0.4, noise=torch.from_numpy(noise)).cpu().numpy()
+    np.testing.assert_allclose(got, otv.add_continuous_metadata_noise_subset(cond, cont_idx, 0.4, noise), rtol=1e-6, atol=1e-6)
+    rnd = rng.random((2, B, T)).astype(np.float32)
+    base = np.stack([rng.integers(0, classes[c] - 1, (B, T)) for c in cat_idx]).astype(np.int64)
+    gotf = dpp.flip_categorical_metadata_subset(cd, cat_idx, 0.2, classes, rand=list(torch.from_numpy(rnd)), base=list(torch.from_numpy(base)))
+    assert np.array_equal(gotf.cpu().numpy(), otv.flip_categorical_metadata_subset(cond, cat_idx, 0.2, classes, rnd, base))
+    # device draws
+    g = torch.Generator(device=dev).manual_seed(3)
+    nz = dpp.add_continuous_metadata_noise_subset(cd, cont_idx, 0.4, generator=g).cpu().numpy()
+    other = [c for c in range(F) if c not in cont_idx]
+    assert np.array_equal(nz[:, :, other], cond[:, :, other])
+    d = (nz - cond)[:, :, cont_idx].reshape(-1, len(cont_idx))
+    want = 0.4 * cond[:, :, cont_idx].reshape(-1, len(cont_idx)).std(0, ddof=1)
+    np.testing.assert_allclose(d.std(0), want, rtol=2e-2)
+    fl = dpp.flip_categorical_metadata_subset(cd, cat_idx, 0.2, classes, generator=g).cpu().numpy()
+    other = [c for c in range(F) if c not in cat_idx]
+    assert np.array_equal(fl[:, :, other], cond[:, :, other])
+    for c in cat_idx:
+        changed = fl[:, :, c] != cond[:, :, c]
+        assert abs(changed.mean() - 0.2) < 0.01
+        assert fl[:, :, c].min() >= 0 and fl[:, :, c].max() <= classes[c] - 1 and np.array_equal(fl[:, :, c], np.trunc(fl[:, :, c]))
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_linear_bwd_weight_skinny_strided_operands(ops, dev, prec):
     """Extents <= 8 on either side (input_proj, fc, time_encode) with operands that are column slices of wider

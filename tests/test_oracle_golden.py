@@ -242,3 +242,23 @@ def test_num_windows_follows_the_reference_loop():
             for stride in (1, 5, 12, 100):
                 want = len(owin.sliding_window(np.zeros((rows, 1)), T, stride)) if rows >= T else 0
                 assert num_windows(rows, T, stride) == want, (rows, T, stride)
+
+
+# ---------------------------------------------------------------------------- TV-MCG corruption helpers
+@pytest.mark.parametrize("name", ["tvmcg_mixed", "tvmcg_skip"])
+def test_tvmcg_corruption_matches_reference(name):
+    """oracle.tvmcg vs dataprovider_pypots.add_continuous_metadata_noise_subset / flip_categorical_metadata_subset
+    run by the reference on the recorded draws.  Flipped codes: exact.  Noisy columns: 1e-6 relative (the
+    column standard deviation is a float64 reduction rounded to float32 on both sides; observed: exact)."""
+    from oracle import tvmcg as otv
+    z, meta = fu.load(name)
+    classes = {int(k): v for k, v in meta["classes"].items()}
+    noisy = otv.add_continuous_metadata_noise_subset(z["cond"], meta["cont_idx"], meta["level"], z["noise"])
+    np.testing.assert_allclose(noisy, z["noisy"], rtol=1e-6, atol=1e-6)
+    untouched = [c for c in range(meta["F"]) if c not in meta["cont_idx"]]
+    assert np.array_equal(noisy[:, :, untouched], z["cond"][:, :, untouched])
+    flipped = otv.flip_categorical_metadata_subset(z["cond"], meta["cat_idx"], meta["p"], classes, z["rand"], z["base"])
+    assert np.array_equal(flipped, z["flipped"])
+    # level / p of zero hand back the input itself
+    assert otv.add_continuous_metadata_noise_subset(z["cond"], meta["cont_idx"], 0.0, None) is not None
+    assert np.array_equal(otv.flip_categorical_metadata_subset(z["cond"], meta["cat_idx"], 0.0, classes, None, None), z["cond"])

@@ -380,6 +380,29 @@ def gather_windows(table, idx, T, stride, out):
     _call("tad_gather_windows", B, T, F, stride, table.data_ptr(), table.stride(0), idx.data_ptr(), out.data_ptr(), _stream())
 
 
+def metadata_noise(cond, cols, noise, level, out):
+    """out = cond with level * (column std + 1e-8) * noise added on the columns ``cols`` (reference
+    dataprovider_pypots.py:149-180).  cond/out [..., F] float32, noise [rows, len(cols)] float32."""
+    cp, rows, F, ld = as2d(cond)
+    op, rows2, F2, ldo = as2d(out)
+    n = len(cols)
+    assert rows == rows2 and F == F2 and noise.is_contiguous() and noise.numel() == rows * n and noise.dtype == torch.float32
+    stats = torch.empty(2 * max(n, 1), dtype=torch.float64, device=cond.device)
+    _call("tad_metadata_noise", rows, F, n, _i32(cols), cp, ld, _ptr(noise), float(level), stats.data_ptr(), op, ldo, _stream())
+
+
+def flip_categories(cond, cols, classes, rnd, base, p, out):
+    """out = cond with the codes of the columns ``cols`` flipped to another class where rnd < p (reference
+    dataprovider_pypots.py:182-229).  rnd [len(cols), rows] float32, base [len(cols), rows] int64."""
+    cp, rows, F, ld = as2d(cond)
+    op, rows2, F2, ldo = as2d(out)
+    n = len(cols)
+    assert rows == rows2 and F == F2 and len(classes) == n
+    assert rnd.is_contiguous() and rnd.dtype == torch.float32 and rnd.numel() == n * rows
+    assert base.is_contiguous() and base.dtype == torch.int64 and base.numel() == n * rows
+    _call("tad_flip_categories", rows, F, n, _i32(cols), _i32(classes), cp, ld, _ptr(rnd), _ptr(base), float(p), op, ldo, _stream())
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n
