@@ -195,6 +195,7 @@ class VAETrainer:
         self.b_mask = ws.get("batch.mask", (nb, self.T, self.F))
         self.b_cond = ws.get("batch.cond", (nb, self.T, self.F)) if self.cond_tr is not None else None
         self.all_indices = list(range(self.N))
+        self._next_idx = None
 
     def _loss(self, rows, beta):
         """Combine the (all-reduced) partial sums on the host -> python float total."""
@@ -207,12 +208,16 @@ class VAETrainer:
         """One optimizer step (reference VAE.py:322-354) -> train loss (python float)."""
         eng, plan = self.eng, self.plan
         d = eng.device
-        if idx is None:
-            idx = random.sample(self.all_indices, self.B)
+        lo, hi = plan.lo, plan.hi
+        own_draw = idx is None
+        if own_draw:
+            # drawn while the previous step was still running on the device (see the end of this function)
+            idx_d = self._next_idx if self._next_idx is not None else self._draw_idx()
+            self._next_idx = None
+        else:
+            idx_d = torch.as_tensor(idx[lo:hi], dtype=torch.int64).to(d)
         if eps is None:
             eps = torch.randn(self.B, self.T, eng.lat, device=d)
-        lo, hi = plan.lo, plan.hi
-        idx_d = torch.as_tensor(idx[lo:hi], dtype=torch.int64).to(d)
         eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
         ops.gather_rows(self.inp_tr, idx_d, self.b_inp)
         ops.gather_rows(self.tgt_tr, idx_d, self.b_tgt)
@@ -230,7 +235,16 @@ class VAETrainer:
         eng.backward(beta, rows)
         plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.parts)
         eng.fp.adam(self.lr, weight_decay=self.wd)
+        if own_draw:
+            # the next minibatch's indices (python `random`, the reference's generator for them, VAE.py:340) are
+            # drawn now, while the device works on this step: reading the loss back below blocks the host
+            self._next_idx = self._draw_idx()
         return self._loss(rows, beta)
+
+    def _draw_idx(self):
+        """random.sample of the global batch (reference VAE.py:340) -> this rank's slice, on the device."""
+        idx = random.sample(self.all_indices, self.B)
+        return torch.as_tensor(idx[self.plan.lo:self.plan.hi], dtype=torch.int64).to(self.eng.device)
 
     def eval_loss(self, beta, eps=None):
         """Full validation-set loss under the current weights (reference VAE.py:357-368)."""

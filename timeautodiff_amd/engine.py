@@ -123,6 +123,13 @@ class FlatParams:
         if GRAD_IMMEDIATE:
             self.release()
 
+    def defer_until_release(self, fn, *args, **kwargs):
+        """Queue any launch that is independent of what the current stream does until the next ``join()``; it is
+        issued on the side stream at the next ``release()`` (i.e. beside the next sequence kernel)."""
+        if self.side is None:
+            return fn(*args, **kwargs)
+        self._queued.append((fn, args, kwargs))
+
     def release(self):
         """Issue the queued launches on the side stream; called right before a latency-bound kernel goes to the
         current stream, so that the two run side by side."""
@@ -302,6 +309,7 @@ class RnnStack:
                                  b_hh=fp.p(self.name("bias_hh", layer, d)) if not lstm else None,
                                  out=out[:, d * H:(d + 1) * H], gates=gates[:, sl] if train else None,
                                  cstate=cst[:, d * H:(d + 1) * H] if cst is not None else None, reverse=self.rev[d]))
+            fp.release()
             ops.rnn_fwd(self.cell, prec, B, T, H, dirs)
             inp = out
         return inp
@@ -521,16 +529,14 @@ class DenoiserEngine:
         self._saved = (x2, t1, i1, ti2, B, T)
         cat = ws.get("cat", (BT, 4 * H))
         ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), cat[:, :H])
+        # the time / step encodings depend on nothing the conditioning path computes: they are queued for the side
+        # stream and run beside the conditioning GRU's first sequence kernel
+        ta = ws.get("ta", (BT, H))
+        fp.defer_until_release(self._encodings, cat, ta, t1, i1, ti2, BT)
         emb = self.emb.forward(c2, ws, "emb")
         gout = self.gru.forward(emb, B, T, ws, "gru", train)
         ops.linear_fwd(prec, gout, fp.p("cond_output.weight"), fp.p("cond_output.bias"), cat[:, :H], accumulate=True)
-        ops.posenc_fwd(t1, 1, BT, H, 1.0, fp.p("t_enc.linear_proj.weight"), fp.p("t_enc.linear_proj.bias"), self.scale_t,
-                       self.shift_t, cat[:, H:2 * H])
-        ops.posenc_fwd(i1, 1, BT, H, 1.0 / self.i_max, fp.p("i_enc.linear_proj.weight"), fp.p("i_enc.linear_proj.bias"),
-                       self.scale_i, self.shift_i, cat[:, 2 * H:3 * H])
-        ta = ws.get("ta", (BT, H))
-        ops.linear_fwd(prec, ti2, fp.p("time_encode.0.weight"), fp.p("time_encode.0.bias"), ta, act=ACT_RELU)
-        ops.linear_fwd(prec, ta, fp.p("time_encode.2.weight"), fp.p("time_encode.2.bias"), cat[:, 3 * H:])
+        fp.join()
         pa = ws.get("pa", (BT, H))
         ops.linear_fwd(prec, cat, fp.p("proj.net.0.weight"), fp.p("proj.net.0.bias"), pa, act=ACT_RELU)
         lout = self.lstm.forward(pa, B, T, ws, "lstm", train)
@@ -540,6 +546,16 @@ class DenoiserEngine:
         pred = ws.get("pred", (BT, K))
         ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
         return pred.view(B, T, K)
+
+    def _encodings(self, cat, ta, t1, i1, ti2, BT):
+        """t_enc | i_enc | time_encode -> columns H..4H of the input of `proj` (reference DIFF.py:199-204)."""
+        fp, prec, H = self.fp, self.prec, self.H
+        ops.posenc_fwd(t1, 1, BT, H, 1.0, fp.p("t_enc.linear_proj.weight"), fp.p("t_enc.linear_proj.bias"), self.scale_t,
+                       self.shift_t, cat[:, H:2 * H])
+        ops.posenc_fwd(i1, 1, BT, H, 1.0 / self.i_max, fp.p("i_enc.linear_proj.weight"), fp.p("i_enc.linear_proj.bias"),
+                       self.scale_i, self.shift_i, cat[:, 2 * H:3 * H])
+        ops.linear_fwd(prec, ti2, fp.p("time_encode.0.weight"), fp.p("time_encode.0.bias"), ta, act=ACT_RELU)
+        ops.linear_fwd(prec, ta, fp.p("time_encode.2.weight"), fp.p("time_encode.2.bias"), cat[:, 3 * H:])
 
     # -- backward -----------------------------------------------------------
     def backward(self, dpred):
