@@ -446,7 +446,7 @@ class EmbBlock:
         fp.defer(ops.linear_bwd_weight, prec, da2, ecat, fp.g(pre + "mlp_output.0.weight"), db=fp.g(pre + "mlp_output.0.bias"))
         if nd:
             gt = fp.ggroup(f"{pre}embeddings_list.0.weight", sum(self.cards), E)
-            ops.embed_bwd(x[:, :nd], decat[:, :nd * E], gt, self.tab_off, self.cards, E)
+            fp.defer(ops.embed_bwd, x[:, :nd], decat[:, :nd * E], gt, self.tab_off, self.cards, E)
         if nn:
             feats = ws.get(f"{tag}.feats", (rows, 16 * nn))
             z1 = ws.get(f"{tag}.z1", (rows, 16 * nn))
@@ -515,12 +515,14 @@ class DenoiserEngine:
         BT = B * T
         if cond.shape[1] != T:
             raise ValueError("cond must cover the same T steps as x (right-padding a shorter cond is not supported)")
+        # the kernel-side weight images depend on the parameters only: a dozen small launches that run on the side
+        # stream beside the embedding block; joined before the first recurrent layer needs them
         if train:
-            self.lstm.pack()
-            self.gru.pack()
+            fp.defer(self.lstm.pack)
+            fp.defer(self.gru.pack)
         else:
-            self.lstm.pack_fwd_only()
-            self.gru.pack_fwd_only()
+            fp.defer(self.lstm.pack_fwd_only)
+            fp.defer(self.gru.pack_fwd_only)
         x2 = x.reshape(BT, K)
         t1 = t.reshape(BT)
         i1 = i_f.reshape(BT)
@@ -529,11 +531,12 @@ class DenoiserEngine:
         self._saved = (x2, t1, i1, ti2, B, T)
         cat = ws.get("cat", (BT, 4 * H))
         ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), cat[:, :H])
+        emb = self.emb.forward(c2, ws, "emb")
+        fp.join()
         # the time / step encodings depend on nothing the conditioning path computes: they are queued for the side
         # stream and run beside the conditioning GRU's first sequence kernel
         ta = ws.get("ta", (BT, H))
         fp.defer_until_release(self._encodings, cat, ta, t1, i1, ti2, BT)
-        emb = self.emb.forward(c2, ws, "emb")
         gout = self.gru.forward(emb, B, T, ws, "gru", train)
         ops.linear_fwd(prec, gout, fp.p("cond_output.weight"), fp.p("cond_output.bias"), cat[:, :H], accumulate=True)
         fp.join()
@@ -581,10 +584,10 @@ class DenoiserEngine:
         _lin_bwd(fp, prec, dpz, cat, fp.p("proj.net.0.weight"), fp.g("proj.net.0.weight"), fp.g("proj.net.0.bias"), dx=dcat)
         dxh = dcat[:, :H]
         _lin_bwd(fp, prec, dxh, x2, None, fp.g("input_proj.net.0.weight"), fp.g("input_proj.net.0.bias"))
-        ops.colsum(dcat[:, H:H + Lh], out_sum=fp.g("t_enc.linear_proj.bias"), row_scale=t1, scale_mul=1.0,
-                   out_wsum=fp.g("t_enc.linear_proj.weight"))
-        ops.colsum(dcat[:, 2 * H:2 * H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
-                   out_wsum=fp.g("i_enc.linear_proj.weight"))
+        fp.defer(ops.colsum, dcat[:, H:H + Lh], out_sum=fp.g("t_enc.linear_proj.bias"), row_scale=t1, scale_mul=1.0,
+                 out_wsum=fp.g("t_enc.linear_proj.weight"))
+        fp.defer(ops.colsum, dcat[:, 2 * H:2 * H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
+                 out_wsum=fp.g("i_enc.linear_proj.weight"))
         dtenc = dcat[:, 3 * H:]
         dta = ws.get("dta", (BT, H))
         _lin_bwd(fp, prec, dtenc, ta, fp.p("time_encode.2.weight"), fp.g("time_encode.2.weight"), fp.g("time_encode.2.bias"),
@@ -788,12 +791,10 @@ class VAEEngine:
         fp, ws, prec, H, Lt = self.fp, self.ws, self.prec, self.H, self.lat
         B, T, _ = inp.shape
         BT = B * T
-        if train:
-            self.enc.pack()
-        else:
-            self.enc.pack_fwd_only()
+        fp.defer(self.enc.pack if train else self.enc.pack_fwd_only)       # beside the embedding block
         x2 = inp.reshape(BT, self.F)
         e = self.emb.forward(x2, ws, "emb")
+        fp.join()
         hh = self.enc.forward(e, B, T, ws, tag, train)
         mu = ws.get("mu", (BT, Lt))
         lv = ws.get("lv", (BT, Lt))
