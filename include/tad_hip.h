@@ -183,6 +183,17 @@ int tad_add_noise(int64_t B, int64_t T, int64_t K, const float* x0, const float*
 int tad_sampler_update(int64_t n, float* x, const float* pred, const float* z, float c1, float c2, float c3,
                        int last, tad_stream_t stream);
 
+/* Tail of one reverse step fused into one pass over the recurrent output h [rows, D] (row stride ldh):
+ * LayerNorm (DIFF.py:183, 221; eps) -> fc (DIFF.py:184, 223; fc_w [K, D], fc_b [K]) -> the update of
+ * tad_sampler_update on x [rows, K] with z [rows, K] (DIFF.py:348-351) -> input_proj of the UPDATED x for the
+ * next step (DIFF.py:198; w_in [H, K], b_in [H]) into xh [rows, H] (row stride ldxh).  prec = TAD_BF16 rounds
+ * the operands of the two projections to bf16 like the matrix products they replace.  D <= 1024, K <= 8,
+ * H*(K+1) <= 12288; other shapes take tad_layernorm_fwd + tad_linear_fwd + tad_sampler_update. */
+int tad_sampler_tail(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
+                     const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
+                     float c1, float c2, float c3, int last, const float* w_in, const float* b_in, float* xh,
+                     int64_t ldxh, tad_stream_t stream);
+
 /* Denoiser loss (DIFF.py:259-260) and its gradient: loss_sum[0] += sum (pred-target)^2,
  * dpred = grad_scale * (pred - target)  (grad_scale = 2/numel of the GLOBAL batch). */
 int tad_mse_loss(int64_t n, const float* pred, const float* target, float grad_scale, float* dpred,

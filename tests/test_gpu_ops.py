@@ -722,6 +722,36 @@ def test_gather_windows_fullsize_vs_oracle(ops, dev):
         dpp.WindowedTable(D(table[:5], dev), T, 1)           # fewer rows than one window: the reference's stack([]) error
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("shape", [(1000, 400, 6, 200, False), (77, 1024, 4, 512, True), (130, 48, 8, 24, False)])
+def test_sampler_tail_equals_the_four_launches(ops, dev, prec, shape):
+    """tad_sampler_tail (LayerNorm -> fc -> sampler update -> next input_proj in one pass) against the four entry
+    points it replaces, on the same inputs: 1e-5 relative (same roundings, different summation order in the two
+    projections)."""
+    rows, Dm, K, H, last = shape
+    rng = np.random.default_rng(5)
+    h = D(rng.standard_normal((rows, Dm)).astype(np.float32) * 3 + 1, dev)
+    gamma, beta = D(rng.standard_normal(Dm).astype(np.float32), dev), D(rng.standard_normal(Dm).astype(np.float32), dev)
+    fc_w, fc_b = D(rng.standard_normal((K, Dm)).astype(np.float32) * 0.1, dev), D(rng.standard_normal(K).astype(np.float32), dev)
+    w_in, b_in = D(rng.standard_normal((H, K)).astype(np.float32), dev), D(rng.standard_normal(H).astype(np.float32), dev)
+    x0 = D(rng.standard_normal((rows, K)).astype(np.float32), dev)
+    z = D(rng.standard_normal((rows, K)).astype(np.float32), dev)
+    c1, c2, c3 = 1.02, 0.31, 0.2
+    ln = torch.empty(rows, Dm, device=dev)
+    pred = torch.empty(rows, K, device=dev)
+    xa, xha = x0.clone(), torch.empty(rows, H, device=dev)
+    ops.layernorm_fwd(h, gamma, beta, ln, None)
+    ops.linear_fwd(prec, ln, fc_w, fc_b, pred)
+    ops.sampler_update(xa, pred, z, c1, c2, c3, last)
+    ops.linear_fwd(prec, xa, w_in, b_in, xha)
+    xb, xhb = x0.clone(), torch.full((rows, H + 3), 7.0, device=dev)[:, :H]        # strided result rows
+    ops.sampler_tail(prec, h, gamma, beta, fc_w, fc_b, xb, z, c1, c2, c3, last, w_in, b_in, xhb)
+    tol = 1e-5 if prec == 0 else 2e-3       # bf16: a last-bit difference of the updated x can flip its bf16 rounding
+    assert float((xa - xb).abs().max()) <= 1e-5 * float(xa.abs().max())
+    assert float((xha - xhb).abs().max()) <= tol * float(xha.abs().max())
+    assert torch.all(xhb._base[:, H:] == 7.0)
+
+
 # ---------------------------------------------------------------------------- TV-MCG metadata corruption
 @pytest.mark.parametrize("name", ["tvmcg_mixed", "tvmcg_skip"])
 def test_tvmcg_corruption_vs_reference_golden(ops, dev, name):

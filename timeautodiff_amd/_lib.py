@@ -49,6 +49,7 @@ PROTOTYPES = {
     "tad_rnn_pack_weights": (_i, [_i, _i64, _i, _p, _p, _p, _p]),
     "tad_add_noise": (_i, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "tad_sampler_update": (_i, [_i64, _p, _p, _p, _f, _f, _f, _i, _p]),
+    "tad_sampler_tail": (_i, [_i, _i64, _i, _i, _i, _p, _i64, _p, _p, _f, _p, _p, _p, _p, _f, _f, _f, _i, _p, _p, _p, _i64, _p]),
     "tad_mse_loss": (_i, [_i64, _p, _p, _f, _p, _p, _p]),
     "tad_sincos_features": (_i, [_i64, _i, _p, _i64, _p, _i64, _p]),
     "tad_embed_fwd": (_i, [_i64, _i, _i, _p, _i64, _p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _p, _i64, _p]),

@@ -222,6 +222,96 @@ __global__ void layernorm_fwd_kernel(int64_t rows, int D, const float* __restric
   }
 }
 
+// Tail of one reverse-diffusion step, one wave per row (= one (sequence, time) pair): LayerNorm of the recurrent
+// output row (kept in registers, as layernorm_fwd_kernel), the K-wide output projection, the sampler update of
+// the row's K latent values, and the input projection of the UPDATED values for the next step.  round16: the
+// operands of the two projections are rounded to bf16 where a bf16 matrix product would round them.
+template <int NC, int KMAX>
+__global__ void sampler_tail_kernel(int64_t rows, int D, int K, int H, int round16, const float* __restrict__ h, int64_t ldh,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                    const float* __restrict__ fcw, const float* __restrict__ fcb, float* __restrict__ x,
+                                    const float* __restrict__ z, float c1, float c2, float c3, int last,
+                                    const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                    float* __restrict__ xh, int64_t ldxh) {
+  extern __shared__ float tail_lds[];          // w_in [H, K] (rounded), then b_in [H]
+  for (int e = threadIdx.x; e < H * K; e += blockDim.x) tail_lds[e] = round16 ? (float)(bf16_t)w_in[e] : w_in[e];
+  for (int e = threadIdx.x; e < H; e += blockDim.x) tail_lds[H * K + e] = b_in[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float gm[NC], bt[NC], wk[KMAX][NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    gm[i] = c < D ? gamma[c] : 0.f;
+    bt[i] = c < D ? beta[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float w = (c < D && k < K) ? fcw[(int64_t)k * D + c] : 0.f;
+      wk[k][i] = round16 ? (float)(bf16_t)w : w;
+    }
+  }
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float* hr = h + r * ldh;
+    float xv[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = c < D ? hr[c] : 0.f;
+      if (c < D) s += xv[i];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const float dlt = xv[i] - mean;
+      if (lane + 64 * i < D) v += dlt * dlt;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      float y = (xv[i] - mean) * rstd * gm[i] + bt[i];
+      if (round16) y = (float)(bf16_t)y;
+      if (lane + 64 * i >= D) y = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) acc[k] += y * wk[k][i];
+    }
+    float mine = 0.f;                            // lane k < K ends up with the updated x[r, k]
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        const float p = wave_sum(acc[k]) + fcb[k];
+        if (lane == k) {
+          const int64_t e = r * K + k;
+          // same operation order as sampler_update_kernel
+          float nv = __fadd_rn(__fmul_rn(c1, __fsub_rn(x[e], __fmul_rn(c2, p))), __fmul_rn(c3, z[e]));
+          if (last) nv = __fmul_rn(c1, __fsub_rn(nv, __fmul_rn(c2, p)));
+          x[e] = nv;
+          mine = nv;
+        }
+      }
+    }
+    float xn[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float t = __shfl(mine, k, 64);
+      xn[k] = round16 ? (float)(bf16_t)t : t;
+    }
+    for (int u = lane; u < H; u += 64) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) a += xn[k] * tail_lds[u * K + k];
+      xh[r * ldxh + u] = a + tail_lds[H * K + u];
+    }
+  }
+}
+
 // One wave per row.  The column sums (dgamma, dbeta) are kept per lane over the wave's rows, combined over
 // the workgroup's waves in LDS, and added to the result with one atomic per column and workgroup.
 template <int NC>
@@ -372,6 +462,28 @@ extern "C" int tad_sampler_update(int64_t n, float* x, const float* pred, const 
   TAD_CHECK(n >= 0 && x && pred && z, "tad_sampler_update: bad arguments");
   if (n == 0) return TAD_OK;
   hipLaunchKernelGGL(sampler_update_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, x, pred, z, c1, c2, c3, last);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_sampler_tail(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
+                                const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
+                                float c1, float c2, float c3, int last, const float* w_in, const float* b_in, float* xh,
+                                int64_t ldxh, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && D > 0 && D <= 1024 && K > 0 && K <= 8 && H > 0 && (int64_t)H * (K + 1) <= 12288,
+            "tad_sampler_tail: supported D <= 1024, K <= 8, H*(K+1) <= 12288 (got D=%d K=%d H=%d)", D, K, H);
+  TAD_CHECK(h && gamma && beta && fc_w && fc_b && x && z && w_in && b_in && xh && ldh >= D && ldxh >= H, "tad_sampler_tail: bad arguments");
+  if (rows == 0) return TAD_OK;
+  int64_t g = cdiv64(rows, EW_BLOCK / 64);
+  if (g > 1024) g = 1024;
+  const int nc = (int)cdiv64(D, 64);
+  const size_t lds = sizeof(float) * (size_t)H * (K + 1);
+  const int r16 = prec == TAD_BF16 ? 1 : 0;
+#define TAIL(NC) hipLaunchKernelGGL((sampler_tail_kernel<NC, 8>), dim3((unsigned)g), dim3(EW_BLOCK), lds, EW_STREAM, rows, D, K, H, r16, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, c1, c2, c3, last, w_in, b_in, xh, ldxh)
+  if (nc <= 2) TAIL(2);
+  else if (nc <= 8) TAIL(8);
+  else TAIL(16);
+#undef TAIL
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

@@ -15,6 +15,8 @@ ALIGN = 64  # floats (256 B)
 GRAD_STREAM = os.environ.get("TAD_GRAD_STREAM", "1") != "0"
 # chunks of the sampling batch that walk the reverse loop concurrently (1 = the whole batch on the current stream)
 SAMPLE_STREAMS = int(os.environ.get("TAD_SAMPLE_STREAMS", "2"))
+# TAD_SAMPLE_FUSED_TAIL=0: LayerNorm, fc, the sampler update and the next input_proj as four launches instead of one
+SAMPLE_FUSED_TAIL = os.environ.get("TAD_SAMPLE_FUSED_TAIL", "1") != "0"
 # TAD_SAMPLE_GRAPH=1: replay the reverse loop as one captured HIP graph per batch shape instead of enqueueing it kernel
 # by kernel (off by default: at 1k sequences the loop is device-bound and the graph measured no faster)
 SAMPLE_GRAPH = os.environ.get("TAD_SAMPLE_GRAPH", "0") == "1"
@@ -719,16 +721,27 @@ class DenoiserEngine:
                        self.scale_i, self.shift_i, ie)
         V = ws.get("s.V", (S, H))
         ops.linear_fwd(prec, ie, wp[:, 2 * H:3 * H], None, V)
-        return dict(x2=x2, B=B, T=T, ws=ws, pinv=pinv, V=V, wp=wp, z=z_all, xh=ws.get("s.xh", (BT, H)), pa=ws.get("pa", (BT, H)),
-                    ln=ws.get("ln", (BT, 2 * H)), pred=ws.get("pred", (BT, K)))
+        xh = ws.get("s.xh", (BT, H))
+        fused = SAMPLE_FUSED_TAIL and ops.sampler_tail_supported(2 * H, K, H)
+        if fused:       # the tail of every step leaves input_proj of the updated x behind; the first step needs it up front
+            ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
+        return dict(x2=x2, B=B, T=T, ws=ws, pinv=pinv, V=V, wp=wp, z=z_all, xh=xh, pa=ws.get("pa", (BT, H)),
+                    ln=ws.get("ln", (BT, 2 * H)), pred=ws.get("pred", (BT, K)), fused=fused)
 
     def _sample_step(self, st, s, coef):
         """Reverse step s for the sequences of one ``_sample_setup`` state, on the current stream."""
         fp, prec, H = self.fp, self.prec, self.H
         x2, xh, pa, ln, pred = st["x2"], st["xh"], st["pa"], st["ln"], st["pred"]
-        ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
+        if not st["fused"]:
+            ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
         ops.linear_fwd(prec, xh, st["wp"][:, :H], st["V"][s], pa, act=ACT_RELU, residual=st["pinv"])
         lout = self.lstm.forward(pa, st["B"], st["T"], st["ws"], "lstm", False)
+        if st["fused"]:
+            # LayerNorm -> fc -> update of x -> input_proj of the updated x for the next step, one pass over lout
+            ops.sampler_tail(prec, lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), fp.p("fc.weight"), fp.p("fc.bias"),
+                             x2, st["z"][s], coef[0][s], coef[1][s], coef[2][s], s == 0, fp.p("input_proj.net.0.weight"),
+                             fp.p("input_proj.net.0.bias"), xh)
+            return
         ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, None)
         ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
         ops.sampler_update(x2, pred, st["z"][s], coef[0][s], coef[1][s], coef[2][s], s == 0)

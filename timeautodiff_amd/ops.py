@@ -403,6 +403,22 @@ def flip_categories(cond, cols, classes, rnd, base, p, out):
     _call("tad_flip_categories", rows, F, n, _i32(cols), _i32(classes), cp, ld, _ptr(rnd), _ptr(base), float(p), op, ldo, _stream())
 
 
+def sampler_tail_supported(D, K, H):
+    return D <= 1024 and K <= 8 and H * (K + 1) <= 12288
+
+
+def sampler_tail(prec, h, gamma, beta, fc_w, fc_b, x, z, c1, c2, c3, last, w_in, b_in, xh, eps=1e-5):
+    """LayerNorm(h) -> fc -> sampler update of x (in place, with noise z) -> xh = input_proj(updated x), one launch
+    (reference DIFF.py:221-223, 348-351, 198)."""
+    hp, rows, D, ldh = as2d(h)
+    xp, rows2, H, ldxh = as2d(xh)
+    K = fc_w.shape[0]
+    assert rows == rows2 and fc_w.shape == (K, D) and w_in.shape == (H, K) and fc_w.is_contiguous() and w_in.is_contiguous()
+    assert x.is_contiguous() and z.is_contiguous() and x.numel() == rows * K and z.numel() == rows * K
+    _call("tad_sampler_tail", prec, rows, D, K, H, hp, ldh, _ptr(gamma), _ptr(beta), float(eps), _ptr(fc_w), _ptr(fc_b), _ptr(x),
+          _ptr(z), float(c1), float(c2), float(c3), int(bool(last)), _ptr(w_in), _ptr(b_in), xp, ldxh, _stream())
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n
