@@ -612,7 +612,10 @@ extern "C" int tad_layernorm_bwd(int64_t rows, int D, const float* dy, int64_t l
   TAD_CHECK(lddy >= D && ldx >= D && lddx >= D, "tad_layernorm_bwd: bad leading dimension");
   if (rows == 0) return TAD_OK;
   int64_t g = cdiv64(rows, EW_BLOCK / 64);
-  if (g > 2048) g = 2048;
+  // six workgroups per CU: measured 139 us at 1536 workgroups against 157 (1024), 174 (2048), 178 (4096) for 98 304 x 400
+  static const char* cap_env = getenv("TAD_LN_BWD_GRID");     // experiments: workgroups of the launch
+  const int64_t cap = cap_env ? atoi(cap_env) : 1536;
+  if (g > cap) g = cap;
   const int nc = (int)cdiv64(D, 64);
 #define LN_BWD(NC) hipLaunchKernelGGL(layernorm_bwd_kernel<NC>, dim3((unsigned)g), dim3(EW_BLOCK), 0, EW_STREAM, rows, D, dy, lddy, x, ldx, gamma, mean_rstd, dx, lddx, dgamma, dbeta)
   if (nc <= 2) LN_BWD(2);
