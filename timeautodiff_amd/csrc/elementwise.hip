@@ -149,14 +149,18 @@ __global__ void embed_bwd_direct_kernel(int64_t rows, int nd, int E, const float
   }
 }
 
+// IT: index type of the flat element counter (uint32_t when rows * H fits: a 64-bit division per element costs more
+// than the rest of the kernel)
+template <typename IT>
 __global__ void posenc_kernel(int64_t rows, int H, const float* __restrict__ t, int64_t ts, float inv_max,
                               const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
                               const float* __restrict__ shift, float* __restrict__ out, int64_t ldo) {
   const int L = H / 2;
-  const int64_t n = rows * H;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = e / H;
-    const int c = (int)(e - r * H);
+  const IT n = (IT)(rows * H);
+  for (IT e = (IT)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (IT)gridDim.x * blockDim.x) {
+    const IT rr = e / (IT)H;
+    const int64_t r = (int64_t)rr;
+    const int c = (int)(e - rr * (IT)H);
     const float tv = t[r * ts];
     float v;
     if (c < L) v = __fadd_rn(__fmul_rn(__fmul_rn(tv, inv_max), w[c]), b[c]);
@@ -565,8 +569,12 @@ extern "C" int tad_posenc_fwd(int64_t rows, int H, const float* t, int64_t t_str
                               tad_stream_t stream) {
   TAD_CHECK(rows >= 0 && H >= 2 && t && w && b && scale && shift && out && ldo >= H, "tad_posenc_fwd: bad arguments");
   if (rows == 0) return TAD_OK;
-  hipLaunchKernelGGL(posenc_kernel, dim3(ew_grid(rows * H)), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max, w, b,
-                     scale, shift, out, ldo);
+  if (rows * H + (int64_t)4096 * EW_BLOCK < ((int64_t)1 << 32))       // the grid-stride counter must not wrap either
+    hipLaunchKernelGGL(posenc_kernel<uint32_t>, dim3(ew_grid(rows * H)), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max,
+                       w, b, scale, shift, out, ldo);
+  else
+    hipLaunchKernelGGL(posenc_kernel<int64_t>, dim3(ew_grid(rows * H)), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max,
+                       w, b, scale, shift, out, ldo);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }
