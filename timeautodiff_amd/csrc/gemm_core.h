@@ -917,9 +917,12 @@ inline Cfg pick_cfg(int prec, int64_t M, int64_t N, int64_t min_wgs) {
   static const char* force = getenv("TAD_GEMM_CFG");     // experiments: W, S, H or T for every bf16 launch
   if (force && prec == TAD_BF16) return force[0] == 'W' ? CFG_W : force[0] == 'S' ? CFG_S : force[0] == 'H' ? CFG_H : CFG_T;
   const TileDim d = tile_dim(big);
-  // a result of at most 128 columns would leave half of the 256-wide tile's matrix-core work on padding
-  static const char* narrow = getenv("TAD_GEMM_NARROW");  // experiments: 0 keeps the wide tile for narrow results
-  if (prec == TAD_BF16 && N <= 128 && !(narrow && narrow[0] == '0')) return CFG_T;
+  // a result of at most 128 columns would leave half of the 256-wide tile's matrix-core work on padding; up to 256
+  // columns (one tile column either way) the narrow tile's three workgroups per CU still measured 0-2 % faster,
+  // from 432 columns on 2 % slower
+  static const char* narrow = getenv("TAD_GEMM_NARROW");  // experiments: widest result that takes the narrow tile (0: none)
+  static const int64_t narrow_max = narrow ? atoi(narrow) : 256;
+  if (prec == TAD_BF16 && N <= narrow_max) return CFG_T;
   if (cdiv64(M, d.bm) * cdiv64(N, d.bn) >= min_wgs) return big;
   return CFG_T;
 }
