@@ -204,8 +204,10 @@ class VAETrainer:
         total, _ = self.eng.total_loss(p[:2 + nc], p[2 + max(nc, 1)], beta, rows)
         return total
 
-    def train_step(self, beta, idx=None, eps=None):
-        """One optimizer step (reference VAE.py:322-354) -> train loss (python float)."""
+    def train_step(self, beta, idx=None, eps=None, prefetch=True):
+        """One optimizer step (reference VAE.py:322-354) -> train loss (python float).  With idx=None the
+        minibatch comes from ``random.sample`` like the reference's; prefetch=False on the last step of a run keeps
+        the state of python's ``random`` where the reference leaves it (no draw for a step that never happens)."""
         eng, plan = self.eng, self.plan
         d = eng.device
         lo, hi = plan.lo, plan.hi
@@ -235,7 +237,7 @@ class VAETrainer:
         eng.backward(beta, rows)
         plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.parts)
         eng.fp.adam(self.lr, weight_decay=self.wd)
-        if own_draw:
+        if own_draw and prefetch:
             # the next minibatch's indices (python `random`, the reference's generator for them, VAE.py:340) are
             # drawn now, while the device works on this step: reading the loss back below blocks the host
             self._next_idx = self._draw_idx()
@@ -309,8 +311,8 @@ def _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epoch
         bar.start()
         task = bar.add_task("[red]Training", total=n_epochs)
     for epoch in range(n_epochs):
-        idx = random.sample(tr.all_indices, batch_size)
-        train_loss = tr.train_step(beta, idx=idx, eps=draw(batch_size))
+        # indices: random.sample inside train_step (reference VAE.py:340), drawn one step ahead while the device works
+        train_loss = tr.train_step(beta, eps=draw(batch_size), prefetch=epoch + 1 < n_epochs)
         if select == "train" and train_loss < best_train:
             best_train = train_loss
             best_flat.copy_(eng.fp.flat)
