@@ -294,6 +294,15 @@ int tad_vae_prepare(int64_t n, const float* resp, const float* cond, const float
 int tad_metadata_noise(int64_t rows, int64_t F, int n_cols, const int32_t* cols, const float* cond, int64_t ld,
                        const float* noise, float level, double* stats, float* out, int64_t ldo, tad_stream_t stream);
 
+/* tad_metadata_noise without the caller-provided workspace: the column statistics live in a 1 KiB array inside
+ * the library's device code (one copy per GPU, held until the process ends), so the call neither takes nor makes
+ * an allocation.  No counterpart in the reference: it is for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  Same arguments and results as
+ * tad_metadata_noise; n_cols beyond 64 is rejected.  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (different streams) race; calls on one stream are ordered and each clears what it uses. */
+int tad_metadata_noise_static(int64_t rows, int64_t F, int n_cols, const int32_t* cols, const float* cond, int64_t ld,
+                              const float* noise, float level, float* out, int64_t ldo, tad_stream_t stream);
+
 /* flip_categorical_metadata_subset (dataprovider_pypots.py:182-229): out = cond, except for the n_cols
  * (<= 64, HOST arrays cols / classes, classes[j] >= 2) selected columns, where
  * code = (int64) cond[r, col] (truncation, as .long()), and

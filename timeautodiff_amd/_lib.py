@@ -67,6 +67,7 @@ PROTOTYPES = {
     "tad_vae_heads_loss": (_i, [_i64, _i, _i, _i, C.POINTER(C.c_int32), _p, _i64, _p, _p, _i64, _f, _f, _f, _p, _p, _p]),
     "tad_vae_prepare": (_i, [_i64, _p, _p, _p, _p, _p, _p]),
     "tad_metadata_noise": (_i, [_i64, _i64, _i, C.POINTER(C.c_int32), _p, _i64, _p, _f, _p, _p, _i64, _p]),
+    "tad_metadata_noise_static": (_i, [_i64, _i64, _i, C.POINTER(C.c_int32), _p, _i64, _p, _f, _p, _i64, _p]),
     "tad_flip_categories": (_i, [_i64, _i64, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _p, _i64, _p, _p, _f, _p, _i64, _p]),
     "tad_heads_to_tensor": (_i, [_i64, _i, _i, _i, C.POINTER(C.c_int32), _p, _i64, _p, _i64, _p]),
 }

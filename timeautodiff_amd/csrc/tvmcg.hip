@@ -6,6 +6,8 @@
 // one pass over all of cond.
 #include <math.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -109,19 +111,21 @@ int fill_cols(ColSet& cs, int n, int F, const int32_t* cols, const int32_t* clas
 
 #define TV_STREAM ((hipStream_t)stream)
 
-extern "C" int tad_metadata_noise(int64_t rows, int64_t F, int n_cols, const int32_t* cols, const float* cond, int64_t ld,
-                                  const float* noise, float level, double* stats, float* out, int64_t ldo,
-                                  tad_stream_t stream) {
-  TAD_CHECK(rows >= 0 && F > 0 && F < (1 << 30) && cond && out && ld >= F && ldo >= F, "tad_metadata_noise: bad arguments rows=%ld F=%ld ld=%ld ldo=%ld",
-            (long)rows, (long)F, (long)ld, (long)ldo);
-  TAD_CHECK(n_cols == 0 || (noise && stats), "tad_metadata_noise: noise and stats are required when columns are selected");
+namespace {
+
+// The three launches of the metadata-noise entry points; `stats` is device memory of 2*n_cols doubles.
+int metadata_noise_launch(const char* who, int64_t rows, int64_t F, int n_cols, const int32_t* cols, const float* cond, int64_t ld,
+                          const float* noise, float level, double* stats, float* out, int64_t ldo, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && F > 0 && F < (1 << 30) && cond && out && ld >= F && ldo >= F, "%s: bad arguments rows=%ld F=%ld ld=%ld ldo=%ld",
+            who, (long)rows, (long)F, (long)ld, (long)ldo);
+  TAD_CHECK(n_cols == 0 || (noise && stats), "%s: noise and stats are required when columns are selected", who);
   ColSet cs;
-  int rc = fill_cols(cs, n_cols, (int)F, cols, nullptr, "tad_metadata_noise");
+  int rc = fill_cols(cs, n_cols, (int)F, cols, nullptr, who);
   if (rc != TAD_OK) return rc;
   if (rows == 0) return TAD_OK;
   if (n_cols > 0) {
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * n_cols, TV_STREAM);
-    TAD_CHECK(e == hipSuccess, "tad_metadata_noise: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    TAD_CHECK(e == hipSuccess, "%s: hipMemsetAsync failed: %s", who, hipGetErrorString(e));
     hipLaunchKernelGGL(colstats_kernel<0>, dim3(tv_grid(rows)), dim3(TV_BLOCK), 0, TV_STREAM, rows, n_cols, cs, cond, ld, stats);
     hipLaunchKernelGGL(colstats_kernel<1>, dim3(tv_grid(rows)), dim3(TV_BLOCK), 0, TV_STREAM, rows, n_cols, cs, cond, ld, stats);
   }
@@ -129,6 +133,55 @@ extern "C" int tad_metadata_noise(int64_t rows, int64_t F, int n_cols, const int
                      noise, level, stats, out, ldo);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
+}
+
+}  // namespace
+
+extern "C" int tad_metadata_noise(int64_t rows, int64_t F, int n_cols, const int32_t* cols, const float* cond, int64_t ld,
+                                  const float* noise, float level, double* stats, float* out, int64_t ldo,
+                                  tad_stream_t stream) {
+  return metadata_noise_launch("tad_metadata_noise", rows, F, n_cols, cols, cond, ld, noise, level, stats, out, ldo, stream);
+}
+
+// ---------------------------------------------------------------------------
+// The same operation for callers that cannot allocate: the column statistics live in a device array of this
+// code object instead of a caller-provided workspace.  Every GPU holds its own copy of the array at its own
+// address; in host code the array's name is only a handle for hipGetSymbolAddress, never a device pointer.
+namespace {
+
+static __device__ __align__(256) double scratch[2 * TV_MAX_COLS];     // 1 KiB per GPU, held until the process ends
+
+constexpr int TV_MAX_DEVICES = 64;
+std::atomic<double*> g_scratch_ptr[TV_MAX_DEVICES];                    // device address of `scratch`, per device
+
+// Device address of this GPU's copy of `scratch` (looked up once per device, with that device current).
+int scratch_address(double** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  TAD_CHECK(e == hipSuccess && dev >= 0 && dev < TV_MAX_DEVICES, "tad_metadata_noise_static: hipGetDevice failed or device %d beyond %d: %s",
+            dev, TV_MAX_DEVICES - 1, hipGetErrorString(e));
+  double* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    void* sym = nullptr;
+    e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+    TAD_CHECK(e == hipSuccess && sym, "tad_metadata_noise_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+    p = reinterpret_cast<double*>(sym);
+    g_scratch_ptr[dev].store(p, std::memory_order_release);            // racing first calls store the same address
+  }
+  *out = p;
+  return TAD_OK;
+}
+
+}  // namespace
+
+extern "C" int tad_metadata_noise_static(int64_t rows, int64_t F, int n_cols, const int32_t* cols, const float* cond,
+                                         int64_t ld, const float* noise, float level, float* out, int64_t ldo,
+                                         tad_stream_t stream) {
+  TAD_CHECK(n_cols >= 0 && n_cols <= TV_MAX_COLS, "tad_metadata_noise_static: %d selected columns exceed the static scratch (at most %d)",
+            n_cols, TV_MAX_COLS);
+  double* stats = nullptr;
+  if (int rc = scratch_address(&stats)) return rc;
+  return metadata_noise_launch("tad_metadata_noise_static", rows, F, n_cols, cols, cond, ld, noise, level, stats, out, ldo, stream);
 }
 
 extern "C" int tad_flip_categories(int64_t rows, int64_t F, int n_cols, const int32_t* cols, const int32_t* classes,
