@@ -36,7 +36,7 @@ typedef void* tad_stream_t;
 
 enum { TAD_OK = 0, TAD_ERR_INVALID = 1, TAD_ERR_LAUNCH = 2 };
 enum { TAD_F32 = 0, TAD_BF16 = 1 };
-enum { TAD_ACT_NONE = 0, TAD_ACT_RELU = 1 };
+enum { TAD_ACT_NONE = 0, TAD_ACT_RELU = 1, TAD_ACT_SILU = 2 /* tad_mm16_nt only */ };
 enum { TAD_CELL_LSTM = 0, TAD_CELL_GRU = 1 };
 
 int tad_abi_version(void);
@@ -95,6 +95,37 @@ int tad_linear_bwd_data_b16(int64_t M, int64_t N, int64_t K, const void* dY16, i
 int tad_linear_bwd_weight_b16(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const float* X,
                               int64_t ldx, float* dW, int64_t ldw, float* db, float* db2, int64_t T,
                               int64_t tshift, const int32_t* gate_map, tad_stream_t stream);
+
+/* Products with BOTH operands stored as bf16 (bf16 matrix cores, fp32 accumulation), staged global -> LDS by
+ * direct-to-LDS loads.  Same nn.Linear call sites as above, for activations that are kept in HBM as bf16.
+ *   C[M,N] = act(A16[M,K] W16[N,K]^T + bias + residual), then zeroed where relu_of[m,n] <= 0.
+ * A16, W16: bf16, 16-byte aligned rows (K, lda, ldw multiples of 8), K <= 1024; N a multiple of 8.  W16 is a PADDED
+ * image: allocated (readable) for N rounded up to a multiple of 64 rows and K rounded up to a multiple of 128
+ * columns (ldw >= that), zeros in columns K.. of every row; rows N.. may hold anything.  bias fp32 [N] or NULL.  residual / relu_of: [M,N] operands of dtype res_dtype / relu_dtype (TAD_F32 or TAD_BF16) or NULL; residual
+ * may alias C.  C: fp32 or bf16 (c_dtype), ldc a multiple of 4.  Z16 (optional, bf16 [M,N]): receives the value
+ * before `act` (the pre-activation a SiLU's backward needs, DIFF.py:58 / VAE.py:81).  act: NONE, RELU or SILU.
+ * With W16 = the transposed weight image this is also the input gradient dX = dY W. */
+int tad_mm16_nt(int64_t M, int64_t N, int64_t K, const void* A16, int64_t lda, const void* W16, int64_t ldw,
+                const float* bias, const void* residual, int res_dtype, int64_t ld_res, const void* relu_of,
+                int relu_dtype, int64_t ld_relu, void* C, int c_dtype, int64_t ldc, void* Z16, int64_t ldz, int act,
+                tad_stream_t stream);
+
+/* Weight gradients with both operands stored as bf16 (autograd of nn.Linear / nn.LSTM / nn.GRU wrt their weights,
+ * same call sites as tad_linear_bwd_weight): for every job k
+ *   C_k[map(a), b] += sum_m A16[m, a0_k + a] * B16_k[m + shift_k, b],   a < na_k, b < nb_k,
+ * where a row m + shift_k that leaves its window of T rows (0 <= (m mod T) + shift_k < T fails) reads as zero: the
+ * h_{t-1} operand of BPTT.  All jobs of a call share A16 (the gate gradients of a recurrent layer feed dW_ih and both
+ * dW_hh), which is then read once from HBM.  db / db2 (or NULL) += the column sums of the job's columns of A16.
+ * gate_map = {H, G, slot0..slot3} maps product row blk*4H + 4u + s to row blk*G*H + slot_s*H + u of C_k / db
+ * (dropped when slot_s < 0); gate_map[0] == 0: rows as they are.  A16, B16: bf16, 16-byte aligned rows; a0, na, nb
+ * multiples of 8.  C_k fp32 (float atomics: sums differ in the last bits from run to run). */
+typedef struct {
+  const void* B16; int64_t ldb; int64_t nb; int64_t shift;
+  float* C; int64_t ldc; float* db; float* db2;
+  int64_t a0, na;
+  int32_t gate_map[6];
+} tad_mm16_tn_job_t;
+int tad_mm16_tn(int64_t M, int64_t T, const void* A16, int64_t lda, int njobs, const tad_mm16_tn_job_t* jobs, tad_stream_t stream);
 
 /* Column sums: out_sum[n] += sum_m dY[m,n]; if out_wsum != NULL also
  * out_wsum[n] += sum_m dY[m,n] * row_scale[m*row_scale_stride] * scale_mul.

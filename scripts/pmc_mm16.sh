@@ -1,0 +1,30 @@
+#!/bin/bash
+# Counter passes over one product of tad_mm16_nt (exp/nt_one.py N K); one rocprofv3 run per pass.
+# usage: scripts/pmc_mm16.sh [N K]
+set -e
+export TMPDIR=/tmp; R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/pmc16; rm -rf $O; mkdir -p $O; cd /tmp
+N=${1:-1600}; K=${2:-400}
+run() { n=$1; shift; timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -- python $R/exp/nt_one.py $N $K > $O/$n.log 2>&1; }
+run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY
+run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_ACTIVE_INST_ANY
+run sq3 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_LEVEL_WAVES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE GRBM_TA_BUSY
+python3 - "$O" <<'PY'
+import csv, glob, sys, collections
+O = sys.argv[1]
+for f in sorted(glob.glob(O + "/**/*_counter_collection.csv", recursive=True)):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if "mm16" not in r["Kernel_Name"]:
+            continue
+        a = acc[r["Counter_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    for k, (n, v) in acc.items():
+        print(f"{k:40s} per launch {v / n:16.0f}   (n={n})")
+for f in sorted(glob.glob(O + "/sq/**/*_kernel_trace.csv", recursive=True)):
+    rows = [r for r in csv.DictReader(open(f)) if "mm16" in r["Kernel_Name"]]
+    if rows:
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+        print("kernel duration ns (profiled):", sum(d) / len(d), "VGPR", rows[0].get("VGPR_Count"), "LDS", rows[0].get("LDS_Block_Size"), "grid", rows[0].get("Grid_Size_X"), "wg", rows[0].get("Workgroup_Size_X"))
+PY

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAD_HIP_LIB") or os.path.join(_HERE, "libtad_hip.so")   # override: A/B builds of the same ABI
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 CELL_LSTM, CELL_GRU = 0, 1
 
 _p = C.c_void_p
@@ -30,6 +30,11 @@ class RnnBwdDir(C.Structure):
                 ("reverse", C.c_int32), ("pad_", C.c_int32)]
 
 
+class TnJob(C.Structure):
+    _fields_ = [("B16", _p), ("ldb", _i64), ("nb", _i64), ("shift", _i64), ("C", _p), ("ldc", _i64), ("db", _p), ("db2", _p),
+                ("a0", _i64), ("na", _i64), ("gate_map", C.c_int32 * 6)]
+
+
 # name -> (restype, argtypes); must list every function declared in include/tad_hip.h
 PROTOTYPES = {
     "tad_abi_version": (_i, []),
@@ -41,6 +46,8 @@ PROTOTYPES = {
     "tad_linear_fwd_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i, _i64, _i, _p]),
     "tad_linear_bwd_data_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "tad_linear_bwd_weight_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, C.POINTER(C.c_int32), _p]),
+    "tad_mm16_nt": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i64, _i, _p]),
+    "tad_mm16_tn": (_i, [_i64, _i64, _p, _i64, _i, C.POINTER(TnJob), _p]),
     "tad_colsum": (_i, [_i64, _i64, _p, _i64, _p, _i64, _f, _p, _p, _p, _p]),
     "tad_rnn_fwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p]),
     "tad_rnn_bwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnBwdDir), _p]),

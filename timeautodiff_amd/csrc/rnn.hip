@@ -622,7 +622,11 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // raises the dynamic-LDS limit of a kernel; `configured` caches the largest size already set
 template <typename K>
-int set_lds(K kernel, size_t bytes, size_t& configured) {
+int set_lds(K kernel, size_t bytes, size_t (&per_device)[64]) {
+  // the attribute belongs to the (kernel, device) pair: remember what was set for the device that is current
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { tad_set_error("set_lds: hipGetDevice failed or device index beyond 63"); return TAD_ERR_LAUNCH; }
+  size_t& configured = per_device[dev];
   if (bytes <= configured) return TAD_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) {
@@ -636,7 +640,7 @@ int set_lds(K kernel, size_t bytes, size_t& configured) {
 template <int CELL, bool BF16, bool ST16, int JPW>
 int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   auto k = rnn_fwd_kernel<CELL, BF16, ST16, JPW>;
-  static size_t configured = 0;
+  static size_t configured[64] = {};
   if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
@@ -647,7 +651,7 @@ int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream
 template <int CELL, bool BF16, bool ST16, int JPW, bool PHASED>
 int launch_bwd(const RnnBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   auto k = rnn_bwd_kernel<CELL, BF16, ST16, JPW, PHASED>;
-  static size_t configured = 0;
+  static size_t configured[64] = {};
   if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, BF16, CELL_GRU, CELL_LSTM, F32, RnnBwdDir, RnnDir  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, BF16, CELL_GRU, CELL_LSTM, F32, RnnBwdDir, RnnDir  # noqa: F401
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -203,6 +203,71 @@ def linear_bwd_data_b16(dy16, w16, dx, relu_of=None, accumulate=False):
         assert Mr == M and Kr == K
     _call("tad_linear_bwd_data_b16", M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream(),
           cost=(2.0 * M * N * K, 2.0 * (M * N + N * K) + 4.0 * M * K * (1 + bool(rp) + bool(accumulate))))
+
+
+def _dt(t):
+    return BF16 if t.dtype == torch.bfloat16 else F32
+
+
+def w16_image(n, k, device):
+    """Zeroed storage of a padded bf16 weight image for mm16_nt: [n rounded up to 64, k rounded up to 128]."""
+    return torch.zeros(-(-n // 64) * 64, -(-k // 128) * 128, dtype=torch.bfloat16, device=device)
+
+
+def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=None):
+    """c = act(a16 w16[:N, :K]^T + bias + residual), zeroed where relu_of <= 0: a16 [M,K] bfloat16, w16 a padded
+    bfloat16 weight image (``w16_image``: rows >= N rounded up to 64, columns K rounded up to 128, zeros beyond K),
+    c [M,N] float32 or bfloat16, residual / relu_of float32 or bfloat16 [M,N]; z_out (bfloat16) receives the value
+    before ``act``."""
+    ap, M, K, lda = as2d(a16, torch.bfloat16)
+    cp, Mc, N, ldc = as2d(c, c.dtype)
+    wp, Nw, Kw, ldw = as2d(w16, torch.bfloat16)
+    assert M == Mc and Nw >= -(-N // 64) * 64 and Kw >= -(-K // 128) * 128 and Kw - K < 128, (a16.shape, w16.shape, c.shape)
+    rp = ldr = up = ldu = zp = ldz = 0
+    rdt = udt = F32
+    if residual is not None:
+        rp, Mr, Nr, ldr = as2d(residual, residual.dtype)
+        rdt = _dt(residual)
+        assert Mr == M and Nr == N
+    if relu_of is not None:
+        up, Mu, Nu, ldu = as2d(relu_of, relu_of.dtype)
+        udt = _dt(relu_of)
+        assert Mu == M and Nu == N
+    if z_out is not None:
+        zp, Mz, Nz, ldz = as2d(z_out, torch.bfloat16)
+        assert Mz == M and Nz == N
+    _call("tad_mm16_nt", M, N, K, ap, lda, wp, ldw, _ptr(bias), rp or None, rdt, ldr, up or None, udt, ldu, cp, _dt(c), ldc,
+          zp or None, ldz, act, _stream(),
+          cost=(2.0 * M * N * K, 2.0 * (M * K + N * K) + c.element_size() * M * N
+                + (residual.element_size() * M * N if residual is not None else 0)
+                + (relu_of.element_size() * M * N if relu_of is not None else 0) + (2.0 * M * N if z_out is not None else 0)))
+
+
+def mm16_tn(a16, jobs, T=0):
+    """Weight gradients from bf16-stored operands, one launch for all ``jobs`` (they share a16 [M, lda]):
+    job = dict(b=bfloat16 [M, nb], c=float32 [rows, nb] (accumulated into), a0=0, na=None (columns of a16), shift=0,
+    db=None, db2=None, gate_map=None).  c += a16[:, a0:a0+na]^T b', b' = b with rows shifted by ``shift`` inside windows
+    of T rows (zeros outside the window)."""
+    ap, M, Na, lda = as2d(a16, torch.bfloat16)
+    arr = (_lib.TnJob * len(jobs))()
+    flops = bytes_ = 0.0
+    for k, j in enumerate(jobs):
+        b, c = j["b"], j["c"]
+        bp, Mb, nb, ldb = as2d(b, torch.bfloat16)
+        cp, rows, nbc, ldc = as2d(c)
+        a0 = j.get("a0", 0)
+        na = j.get("na") or (Na - a0)
+        gm = j.get("gate_map")
+        n_out = na if gm is None else na // 4 * gm[1]
+        assert Mb == M and nbc == nb and rows == n_out, (a16.shape, b.shape, c.shape, a0, na, gm)
+        for d in (j.get("db"), j.get("db2")):
+            assert d is None or (d.is_contiguous() and d.numel() == n_out)
+        g6 = (C.c_int32 * 6)(*( (gm[0], gm[1], *gm[2]) if gm is not None else (0, 0, 0, 0, 0, 0)))
+        arr[k] = _lib.TnJob(bp, ldb, nb, j.get("shift", 0), cp, ldc, _ptr(j.get("db")), _ptr(j.get("db2")), a0, na, g6)
+        flops += 2.0 * M * na * nb
+        bytes_ += 2.0 * M * nb + 4.0 * n_out * nb
+    bytes_ += 2.0 * M * Na
+    _call("tad_mm16_tn", M, T, ap, lda, len(jobs), arr, _stream(), cost=(flops, bytes_))
 
 
 def colsum(dy, out_sum=None, out_sum2=None, row_scale=None, row_scale_stride=1, scale_mul=1.0, out_wsum=None):
