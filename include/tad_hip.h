@@ -110,6 +110,29 @@ int tad_mm16_nt(int64_t M, int64_t N, int64_t K, const void* A16, int64_t lda, c
                 int relu_dtype, int64_t ld_relu, void* C, int c_dtype, int64_t ldc, void* Z16, int64_t ldz, int act,
                 tad_stream_t stream);
 
+/* bf16 copy of an fp32 matrix: dst16[r][c] = bf16(src[r][c]) (round to nearest even), r < rows, c < cols; with
+ * relu_of16 (bf16 [rows, cols], row stride ld_relu) the copy is zero where relu_of16 <= 0 (the ReLU backward of the
+ * layer whose output relu_of16 is).  The bf16
+ * operand of tad_mm16_nt / tad_mm16_tn for activations another kernel left in fp32 (no counterpart in the reference,
+ * which has no reduced-precision mode: the rounding is the one every bf16 product applies to its operands). */
+int tad_cvt_bf16(int64_t rows, int64_t cols, const float* src, int64_t ld_src, void* dst16, int64_t ld_dst,
+                 const void* relu_of16, int64_t ld_relu, tad_stream_t stream);
+
+typedef struct {
+  const float* src;   /* parameter matrix W [n, k], row stride ld_src */
+  int64_t ld_src;
+  int64_t n, k;
+  void* dst;          /* bf16 image: transpose == 0: dst[r][c] = W[r][c] (ld_dst >= k); else dst[c][r] = W[r][c] (ld_dst >= n) */
+  int64_t ld_dst;
+  int32_t transpose;
+  int32_t pad_;
+} tad_pack_w16_job_t;
+/* The bf16 weight images tad_mm16_nt reads (forward: W itself; input gradient: W^T), any number of them in one
+ * launch per 48 jobs.  Only the n x k elements are written: the padding of an image (rows up to a multiple of 64,
+ * row stride a multiple of 128) keeps what its storage was initialised with (zeros).  No counterpart in the
+ * reference: the images are the bf16 compute mode's copies of the nn.Linear / nn.LSTM / nn.GRU weights. */
+int tad_pack_w16(int njobs, const tad_pack_w16_job_t* jobs, tad_stream_t stream);
+
 /* Weight gradients with both operands stored as bf16 (autograd of nn.Linear / nn.LSTM / nn.GRU wrt their weights,
  * same call sites as tad_linear_bwd_weight): for every job k
  *   C_k[map(a), b] += sum_m A16[m, a0_k + a] * B16_k[m + shift_k, b],   a < na_k, b < nb_k,
@@ -147,7 +170,7 @@ typedef struct {
   int64_t ld_xproj;
   const void* w_packed; /* from tad_rnn_pack_weights (forward image) */
   const float* b_hh;    /* GRU: recurrent bias [3H] (r,z,n); LSTM: NULL */
-  float* out;           /* h_t -> out[(b*T+t)*ld_out + u], u < H */
+  float* out;           /* h_t -> out[(b*T+t)*ld_out + u], u < H; may be NULL when out16 is given */
   int64_t ld_out;
   void* gates;          /* training: [B*T, 4H] gate stash (LSTM i,f,g,o; GRU r,z,n,W_hn h+b_hn), row stride ld_gates; NULL = inference */
   int64_t ld_gates;
@@ -155,6 +178,8 @@ typedef struct {
   int64_t ld_c;
   int32_t reverse;      /* 0: t = 0..T-1, 1: t = T-1..0 */
   int32_t pad_;
+  void* out16;          /* optional: h_t once more, rounded to bf16 (the operand of the matrix products that read h), row stride ld_out16 */
+  int64_t ld_out16;
 } tad_rnn_dir_t;
 
 /* nn.LSTM / nn.GRU forward over one layer, ndir (1 or 2) independent directions or
@@ -234,6 +259,9 @@ int tad_mse_loss(int64_t n, const float* pred, const float* target, float grad_s
  * out[r, j*8+k] = sin(2^k pi x[r,j]), out[r, 8n + j*8+k] = cos(...). */
 int tad_sincos_features(int64_t rows, int n_nums, const float* x, int64_t ldx, float* out, int64_t ldo,
                         tad_stream_t stream);
+/* The same values rounded to bf16 (the features feed a matrix product only). */
+int tad_sincos_features_b16(int64_t rows, int n_nums, const float* x, int64_t ldx, void* out16, int64_t ldo,
+                            tad_stream_t stream);
 
 /* Embedding lookups of Embedding_data.forward (DIFF.py:66-75, VAE.py:89-98):
  * out[r, d*E + e] = tables[(tab_off[d] + (int)x[r,d]) * E + e], d < n_disc.
@@ -241,6 +269,9 @@ int tad_sincos_features(int64_t rows, int n_nums, const float* x, int64_t ldx, f
  * tab_off / cards are HOST arrays of n_disc (<= 64) entries, copied into the launch. */
 int tad_embed_fwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* tables,
                   const int32_t* tab_off, const int32_t* cards, float* out, int64_t ldo, tad_stream_t stream);
+/* The same rows rounded to bf16 (they feed a matrix product only). */
+int tad_embed_fwd_b16(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* tables,
+                      const int32_t* tab_off, const int32_t* cards, void* out16, int64_t ldo, tad_stream_t stream);
 /* ... and its autograd: dtables[(tab_off[d]+code)*E + e] += dout[r, d*E+e]. */
 int tad_embed_bwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* dout, int64_t ldo,
                   float* dtables, const int32_t* tab_off, const int32_t* cards, tad_stream_t stream);
@@ -250,10 +281,17 @@ int tad_embed_bwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, 
 int tad_posenc_fwd(int64_t rows, int H, const float* t, int64_t t_stride, float inv_max, const float* w,
                    const float* b, const float* scale, const float* shift, float* out, int64_t ldo,
                    tad_stream_t stream);
+/* The same values rounded to bf16 (in the training step the encodings feed `proj` only, DIFF.py:207-208). */
+int tad_posenc_fwd_b16(int64_t rows, int H, const float* t, int64_t t_stride, float inv_max, const float* w,
+                       const float* b, const float* scale, const float* shift, void* out16, int64_t ldo,
+                       tad_stream_t stream);
 
 /* nn.SiLU (DIFF.py:58, VAE.py:81) forward / backward. */
 int tad_silu_fwd(int64_t n, const float* z, float* a, tad_stream_t stream);
 int tad_silu_bwd(int64_t n, const float* z, const float* da, float* dz, tad_stream_t stream);
+/* Results rounded to bf16: a = silu(z) and dz feed matrix products only (mlp_nums.2, the gradient of mlp_nums.0). */
+int tad_silu_fwd_b16(int64_t n, const float* z, void* a16, tad_stream_t stream);
+int tad_silu_bwd_b16(int64_t n, const float* z, const float* da, void* dz16, tad_stream_t stream);
 
 /* nn.LayerNorm over the last dim D (DIFF.py:183, 221), eps 1e-5; mean_rstd[r] = {mean, rstd}. */
 int tad_layernorm_fwd(int64_t rows, int D, const float* x, int64_t ldx, const float* gamma, const float* beta,

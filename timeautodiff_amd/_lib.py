@@ -21,7 +21,8 @@ _f = C.c_float
 
 class RnnDir(C.Structure):
     _fields_ = [("xproj", _p), ("ld_xproj", _i64), ("w_packed", _p), ("b_hh", _p), ("out", _p), ("ld_out", _i64),
-                ("gates", _p), ("ld_gates", _i64), ("cstate", _p), ("ld_c", _i64), ("reverse", C.c_int32), ("pad_", C.c_int32)]
+                ("gates", _p), ("ld_gates", _i64), ("cstate", _p), ("ld_c", _i64), ("reverse", C.c_int32), ("pad_", C.c_int32),
+                ("out16", _p), ("ld_out16", _i64)]
 
 
 class RnnBwdDir(C.Structure):
@@ -33,6 +34,11 @@ class RnnBwdDir(C.Structure):
 class TnJob(C.Structure):
     _fields_ = [("B16", _p), ("ldb", _i64), ("nb", _i64), ("shift", _i64), ("C", _p), ("ldc", _i64), ("db", _p), ("db2", _p),
                 ("a0", _i64), ("na", _i64), ("gate_map", C.c_int32 * 6)]
+
+
+class PackW16Job(C.Structure):
+    _fields_ = [("src", _p), ("ld_src", _i64), ("n", _i64), ("k", _i64), ("dst", _p), ("ld_dst", _i64),
+                ("transpose", C.c_int32), ("pad_", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every function declared in include/tad_hip.h
@@ -48,6 +54,8 @@ PROTOTYPES = {
     "tad_linear_bwd_weight_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, C.POINTER(C.c_int32), _p]),
     "tad_mm16_nt": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i64, _i, _p]),
     "tad_mm16_tn": (_i, [_i64, _i64, _p, _i64, _i, C.POINTER(TnJob), _p]),
+    "tad_cvt_bf16": (_i, [_i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p]),
+    "tad_pack_w16": (_i, [_i, C.POINTER(PackW16Job), _p]),
     "tad_colsum": (_i, [_i64, _i64, _p, _i64, _p, _i64, _f, _p, _p, _p, _p]),
     "tad_rnn_fwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p]),
     "tad_rnn_bwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnBwdDir), _p]),
@@ -59,11 +67,16 @@ PROTOTYPES = {
     "tad_sampler_tail": (_i, [_i, _i64, _i, _i, _i, _p, _i64, _p, _p, _f, _p, _p, _p, _p, _f, _f, _f, _i, _p, _p, _p, _i64, _p]),
     "tad_mse_loss": (_i, [_i64, _p, _p, _f, _p, _p, _p]),
     "tad_sincos_features": (_i, [_i64, _i, _p, _i64, _p, _i64, _p]),
+    "tad_sincos_features_b16": (_i, [_i64, _i, _p, _i64, _p, _i64, _p]),
     "tad_embed_fwd": (_i, [_i64, _i, _i, _p, _i64, _p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _p, _i64, _p]),
+    "tad_embed_fwd_b16": (_i, [_i64, _i, _i, _p, _i64, _p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _p, _i64, _p]),
     "tad_embed_bwd": (_i, [_i64, _i, _i, _p, _i64, _p, _i64, _p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _p]),
     "tad_posenc_fwd": (_i, [_i64, _i, _p, _i64, _f, _p, _p, _p, _p, _p, _i64, _p]),
+    "tad_posenc_fwd_b16": (_i, [_i64, _i, _p, _i64, _f, _p, _p, _p, _p, _p, _i64, _p]),
     "tad_silu_fwd": (_i, [_i64, _p, _p, _p]),
     "tad_silu_bwd": (_i, [_i64, _p, _p, _p, _p]),
+    "tad_silu_fwd_b16": (_i, [_i64, _p, _p, _p]),
+    "tad_silu_bwd_b16": (_i, [_i64, _p, _p, _p, _p]),
     "tad_layernorm_fwd": (_i, [_i64, _i, _p, _i64, _p, _p, _f, _p, _i64, _p, _p]),
     "tad_layernorm_bwd": (_i, [_i64, _i, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
     "tad_gather_rows": (_i, [_i64, _i64, _p, _p, _p, _p]),

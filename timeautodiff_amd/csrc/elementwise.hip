@@ -73,7 +73,9 @@ __global__ void mse_loss_kernel(int64_t n, const float* __restrict__ pred, const
 }
 
 // out[r, j*8+k] = sin(2^k pi x[r,j]);  out[r, 8n + j*8+k] = cos(...)
-__global__ void sincos_kernel(int64_t rows, int nn, const float* __restrict__ x, int64_t ldx, float* __restrict__ out,
+// OT: element type of the result (float, or bf16_t where only matrix products read it)
+template <typename OT>
+__global__ void sincos_kernel(int64_t rows, int nn, const float* __restrict__ x, int64_t ldx, OT* __restrict__ out,
                               int64_t ldo) {
   const int64_t n = rows * nn * 8;
   const float pi = 3.14159265358979323846f;
@@ -85,8 +87,8 @@ __global__ void sincos_kernel(int64_t rows, int nn, const float* __restrict__ x,
     const float ang = __fmul_rn(freq, x[r * ldx + j]);
     float s, co;
     sincosf(ang, &s, &co);
-    out[r * ldo + c] = s;
-    out[r * ldo + nn * 8 + c] = co;
+    out[r * ldo + c] = (OT)s;
+    out[r * ldo + nn * 8 + c] = (OT)co;
   }
 }
 
@@ -95,8 +97,9 @@ struct DiscMeta {
   int32_t card[MAX_DISC];
 };
 
+template <typename OT>
 __global__ void embed_fwd_kernel(int64_t rows, int nd, int E, const float* __restrict__ x, int64_t ldx,
-                                 const float* __restrict__ tables, DiscMeta m, float* __restrict__ out, int64_t ldo) {
+                                 const float* __restrict__ tables, DiscMeta m, OT* __restrict__ out, int64_t ldo) {
   const int64_t n = rows * nd * E;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / (nd * E);
@@ -104,7 +107,7 @@ __global__ void embed_fwd_kernel(int64_t rows, int nd, int E, const float* __res
     const int d = c / E, q = c - d * E;
     int code = (int)x[r * ldx + d];
     code = min(max(code, 0), m.card[d] - 1);
-    out[r * ldo + c] = tables[((int64_t)m.off[d] + code) * E + q];
+    out[r * ldo + c] = (OT)tables[((int64_t)m.off[d] + code) * E + q];
   }
 }
 
@@ -151,10 +154,10 @@ __global__ void embed_bwd_direct_kernel(int64_t rows, int nd, int E, const float
 
 // IT: index type of the flat element counter (uint32_t when rows * H fits: a 64-bit division per element costs more
 // than the rest of the kernel)
-template <typename IT>
+template <typename IT, typename OT>
 __global__ void posenc_kernel(int64_t rows, int H, const float* __restrict__ t, int64_t ts, float inv_max,
                               const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
-                              const float* __restrict__ shift, float* __restrict__ out, int64_t ldo) {
+                              const float* __restrict__ shift, OT* __restrict__ out, int64_t ldo) {
   const int L = H / 2;
   const IT n = (IT)(rows * H);
   for (IT e = (IT)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (IT)gridDim.x * blockDim.x) {
@@ -165,21 +168,23 @@ __global__ void posenc_kernel(int64_t rows, int H, const float* __restrict__ t, 
     float v;
     if (c < L) v = __fadd_rn(__fmul_rn(__fmul_rn(tv, inv_max), w[c]), b[c]);
     else v = sinf(__fadd_rn(__fmul_rn(tv, scale[c - L]), shift[c - L]));
-    out[r * ldo + c] = v;
+    out[r * ldo + c] = (OT)v;
   }
 }
 
-__global__ void silu_fwd_kernel(int64_t n, const float* __restrict__ z, float* __restrict__ a) {
+template <typename OT>
+__global__ void silu_fwd_kernel(int64_t n, const float* __restrict__ z, OT* __restrict__ a) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const float v = z[e];
-    a[e] = v * sigmoid_acc(v);
+    a[e] = (OT)(v * sigmoid_acc(v));
   }
 }
 
-__global__ void silu_bwd_kernel(int64_t n, const float* __restrict__ z, const float* __restrict__ da, float* __restrict__ dz) {
+template <typename OT>
+__global__ void silu_bwd_kernel(int64_t n, const float* __restrict__ z, const float* __restrict__ da, OT* __restrict__ dz) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const float v = z[e], s = sigmoid_acc(v);
-    dz[e] = da[e] * s * (1.f + v * (1.f - s));
+    dz[e] = (OT)(da[e] * s * (1.f + v * (1.f - s)));
   }
 }
 
@@ -503,13 +508,23 @@ extern "C" int tad_mse_loss(int64_t n, const float* pred, const float* target, f
   return TAD_OK;
 }
 
-extern "C" int tad_sincos_features(int64_t rows, int n_nums, const float* x, int64_t ldx, float* out, int64_t ldo,
-                                   tad_stream_t stream) {
+static int sincos_features(int64_t rows, int n_nums, const float* x, int64_t ldx, void* out, int out_dtype, int64_t ldo, tad_stream_t stream) {
   TAD_CHECK(rows >= 0 && n_nums > 0 && x && out && ldx >= n_nums && ldo >= 16 * n_nums, "tad_sincos_features: bad arguments");
   if (rows == 0) return TAD_OK;
-  hipLaunchKernelGGL(sincos_kernel, dim3(ew_grid(rows * n_nums * 8)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_nums, x, ldx, out, ldo);
+  if (out_dtype == TAD_BF16)
+    hipLaunchKernelGGL(sincos_kernel<bf16_t>, dim3(ew_grid(rows * n_nums * 8)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_nums, x, ldx, (bf16_t*)out, ldo);
+  else
+    hipLaunchKernelGGL(sincos_kernel<float>, dim3(ew_grid(rows * n_nums * 8)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_nums, x, ldx, (float*)out, ldo);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
+}
+extern "C" int tad_sincos_features(int64_t rows, int n_nums, const float* x, int64_t ldx, float* out, int64_t ldo,
+                                   tad_stream_t stream) {
+  return sincos_features(rows, n_nums, x, ldx, out, TAD_F32, ldo, stream);
+}
+extern "C" int tad_sincos_features_b16(int64_t rows, int n_nums, const float* x, int64_t ldx, void* out16, int64_t ldo,
+                                       tad_stream_t stream) {
+  return sincos_features(rows, n_nums, x, ldx, out16, TAD_BF16, ldo, stream);
 }
 
 static int fill_meta(DiscMeta& m, int n_disc, const int32_t* tab_off, const int32_t* cards, const char* who) {
@@ -528,16 +543,28 @@ static int fill_meta(DiscMeta& m, int n_disc, const int32_t* tab_off, const int3
   return TAD_OK;
 }
 
-extern "C" int tad_embed_fwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* tables,
-                             const int32_t* tab_off, const int32_t* cards, float* out, int64_t ldo, tad_stream_t stream) {
+static int embed_fwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* tables,
+                     const int32_t* tab_off, const int32_t* cards, void* out, int out_dtype, int64_t ldo, tad_stream_t stream) {
   TAD_CHECK(rows >= 0 && E > 0 && x && tables && out && ldx >= n_disc && ldo >= (int64_t)n_disc * E, "tad_embed_fwd: bad arguments");
   DiscMeta m{};
   if (int rc = fill_meta(m, n_disc, tab_off, cards, "tad_embed_fwd")) return rc;
   if (rows == 0) return TAD_OK;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(ew_grid(rows * n_disc * E)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_disc, E, x, ldx,
-                     tables, m, out, ldo);
+  if (out_dtype == TAD_BF16)
+    hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(ew_grid(rows * n_disc * E)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_disc, E, x, ldx,
+                       tables, m, (bf16_t*)out, ldo);
+  else
+    hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(ew_grid(rows * n_disc * E)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_disc, E, x, ldx,
+                       tables, m, (float*)out, ldo);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
+}
+extern "C" int tad_embed_fwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* tables,
+                             const int32_t* tab_off, const int32_t* cards, float* out, int64_t ldo, tad_stream_t stream) {
+  return embed_fwd(rows, n_disc, E, x, ldx, tables, tab_off, cards, out, TAD_F32, ldo, stream);
+}
+extern "C" int tad_embed_fwd_b16(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* tables,
+                                 const int32_t* tab_off, const int32_t* cards, void* out16, int64_t ldo, tad_stream_t stream) {
+  return embed_fwd(rows, n_disc, E, x, ldx, tables, tab_off, cards, out16, TAD_BF16, ldo, stream);
 }
 
 extern "C" int tad_embed_bwd(int64_t rows, int n_disc, int E, const float* x, int64_t ldx, const float* dout, int64_t ldo,
@@ -564,25 +591,42 @@ extern "C" int tad_embed_bwd(int64_t rows, int n_disc, int E, const float* x, in
   return TAD_OK;
 }
 
-extern "C" int tad_posenc_fwd(int64_t rows, int H, const float* t, int64_t t_stride, float inv_max, const float* w,
-                              const float* b, const float* scale, const float* shift, float* out, int64_t ldo,
-                              tad_stream_t stream) {
+template <typename OT>
+static int posenc_fwd(int64_t rows, int H, const float* t, int64_t t_stride, float inv_max, const float* w,
+                      const float* b, const float* scale, const float* shift, OT* out, int64_t ldo, tad_stream_t stream) {
   TAD_CHECK(rows >= 0 && H >= 2 && t && w && b && scale && shift && out && ldo >= H, "tad_posenc_fwd: bad arguments");
   if (rows == 0) return TAD_OK;
   if (rows * H + (int64_t)4096 * EW_BLOCK < ((int64_t)1 << 32))       // the grid-stride counter must not wrap either
-    hipLaunchKernelGGL(posenc_kernel<uint32_t>, dim3(ew_grid(rows * H)), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max,
+    hipLaunchKernelGGL((posenc_kernel<uint32_t, OT>), dim3(ew_grid(rows * H)), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max,
                        w, b, scale, shift, out, ldo);
   else
-    hipLaunchKernelGGL(posenc_kernel<int64_t>, dim3(ew_grid(rows * H)), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max,
+    hipLaunchKernelGGL((posenc_kernel<int64_t, OT>), dim3(ew_grid(rows * H)), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max,
                        w, b, scale, shift, out, ldo);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
+}
+extern "C" int tad_posenc_fwd(int64_t rows, int H, const float* t, int64_t t_stride, float inv_max, const float* w,
+                              const float* b, const float* scale, const float* shift, float* out, int64_t ldo,
+                              tad_stream_t stream) {
+  return posenc_fwd<float>(rows, H, t, t_stride, inv_max, w, b, scale, shift, out, ldo, stream);
+}
+extern "C" int tad_posenc_fwd_b16(int64_t rows, int H, const float* t, int64_t t_stride, float inv_max, const float* w,
+                                  const float* b, const float* scale, const float* shift, void* out16, int64_t ldo,
+                                  tad_stream_t stream) {
+  return posenc_fwd<bf16_t>(rows, H, t, t_stride, inv_max, w, b, scale, shift, (bf16_t*)out16, ldo, stream);
 }
 
 extern "C" int tad_silu_fwd(int64_t n, const float* z, float* a, tad_stream_t stream) {
   TAD_CHECK(n >= 0 && z && a, "tad_silu_fwd: bad arguments");
   if (n == 0) return TAD_OK;
-  hipLaunchKernelGGL(silu_fwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, z, a);
+  hipLaunchKernelGGL(silu_fwd_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, z, a);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+extern "C" int tad_silu_fwd_b16(int64_t n, const float* z, void* a16, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && z && a16, "tad_silu_fwd_b16: bad arguments");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(silu_fwd_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, z, (bf16_t*)a16);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }
@@ -590,7 +634,14 @@ extern "C" int tad_silu_fwd(int64_t n, const float* z, float* a, tad_stream_t st
 extern "C" int tad_silu_bwd(int64_t n, const float* z, const float* da, float* dz, tad_stream_t stream) {
   TAD_CHECK(n >= 0 && z && da && dz, "tad_silu_bwd: bad arguments");
   if (n == 0) return TAD_OK;
-  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, z, da, dz);
+  hipLaunchKernelGGL(silu_bwd_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, z, da, dz);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+extern "C" int tad_silu_bwd_b16(int64_t n, const float* z, const float* da, void* dz16, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && z && da && dz16, "tad_silu_bwd_b16: bad arguments");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(silu_bwd_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, z, da, (bf16_t*)dz16);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

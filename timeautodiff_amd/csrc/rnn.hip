@@ -317,6 +317,7 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
         { RSTAMP(qq); q3 = qq; }
 #endif
         const uint32_t ooff = (uint32_t)((4 * half * T + tt) * (int)d.ld_out + u);
+        const uint32_t o16off = (uint32_t)((4 * half * T + tt) * (int)d.ld_out16 + u);
         const uint32_t goff = (uint32_t)(((4 * half * T + tt) * (int)d.ld_gates + 4 * u) * SL::ESZ);
         const uint32_t coff = (uint32_t)((4 * half * T + tt) * (int)d.ld_c + u);
 #pragma unroll
@@ -350,7 +351,8 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
           if (!ok) h = 0.f;
           lds_put<BF16>(nxt, a.lds_ld, row, u, h);
           if (ok) {
-            (d.out + (b0 + cr) * (int64_t)T * d.ld_out)[ooff] = h;
+            if (d.out) (d.out + (b0 + cr) * (int64_t)T * d.ld_out)[ooff] = h;
+            if (d.out16) (reinterpret_cast<bf16_t*>(d.out16) + (b0 + cr) * (int64_t)T * d.ld_out16)[o16off] = (bf16_t)h;
             if (d.gates) {
               unsigned char* gp = reinterpret_cast<unsigned char*>(d.gates) + (b0 + cr) * (int64_t)T * d.ld_gates * SL::ESZ;
               *reinterpret_cast<raw_t*>(gp + goff) = sv;
@@ -708,11 +710,12 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   for (int i = 0; i < ndir; ++i) {
     a.d[i] = dirs[i];
     const tad_rnn_dir_t& di = dirs[i];
-    TAD_CHECK(di.xproj && di.w_packed && di.out, "tad_rnn_fwd: null pointer in dir %d", i);
-    TAD_CHECK(gl_ok(di.xproj, di.ld_xproj, H) && di.ld_out >= H, "tad_rnn_fwd: bad xproj alignment / leading dimension in dir %d", i);
+    TAD_CHECK(di.xproj && di.w_packed && (di.out || di.out16), "tad_rnn_fwd: null pointer in dir %d", i);
+    TAD_CHECK(!di.out16 || di.ld_out16 >= H, "tad_rnn_fwd: bad ld_out16 in dir %d", i);
+    TAD_CHECK(gl_ok(di.xproj, di.ld_xproj, H) && (!di.out || di.ld_out >= H), "tad_rnn_fwd: bad xproj alignment / leading dimension in dir %d", i);
     TAD_CHECK(!di.gates || (gl_ok(di.gates, di.ld_gates, H) && (cell == TAD_CELL_GRU || (di.cstate && di.ld_c >= H))),
               "tad_rnn_fwd: bad gate stash (alignment, leading dimension, or missing cstate) in dir %d", i);
-    TAD_CHECK((5 * T + 1) * (di.ld_xproj + di.ld_out + di.ld_gates + di.ld_c) * 4 < (int64_t)1 << 31, "tad_rnn_fwd: T * ld too large for 32-bit lane offsets");
+    TAD_CHECK((5 * T + 1) * (di.ld_xproj + di.ld_out + di.ld_out16 + di.ld_gates + di.ld_c) * 4 < (int64_t)1 << 31, "tad_rnn_fwd: T * ld too large for 32-bit lane offsets");
   }
   a.B = (int)B; a.T = (int)T; a.H = (int)H; a.NJ = g.NJ; a.nk = g.nkf;
   a.rpw = rows_per_wg(B, ndir);

@@ -21,6 +21,9 @@ SAMPLE_FUSED_TAIL = os.environ.get("TAD_SAMPLE_FUSED_TAIL", "1") != "0"
 # by kernel (off by default: at 1k sequences the loop is device-bound and the graph measured no faster)
 SAMPLE_GRAPH = os.environ.get("TAD_SAMPLE_GRAPH", "0") == "1"
 GRAD_IMMEDIATE = os.environ.get("TAD_GRAD_STREAM", "1") == "1"
+# TAD_MM16=0: bf16 precision keeps every activation in fp32 and uses the fp32-operand product kernels throughout
+# (the path of the fp32 mode with operands rounded inside the kernels; experiments and A/B timing)
+MM16 = os.environ.get("TAD_MM16", "1") != "0"
 
 
 def prec_of(dtype):
@@ -160,6 +163,43 @@ class FlatParams:
         self.version += 1
 
 
+class W16Images:
+    """bf16 images of weight matrices for the bf16-stored-operand products (ops.mm16_nt): ``fwd`` = W [n, k] for
+    y = x W^T, ``tr`` = W^T [k, n] for dx = dy W.  Storage is zero-initialised and padded (rows to a multiple of 64
+    plus one spare block of 64, so that a row slice of an image is an image too; row stride to a multiple of 128);
+    ``pack()`` refreshes all images in one launch when the parameters changed."""
+
+    def __init__(self, fp):
+        self.fp = fp
+        self.items = []
+        self._ver = -1
+
+    @staticmethod
+    def alloc(n, k, device):
+        return torch.zeros(-(-n // 64) * 64 + 64, -(-k // 128) * 128, dtype=torch.bfloat16, device=device)
+
+    def add(self, w, fwd=True, tr=False):
+        """w: float32 [n, k] view of the flat parameter buffer -> dict(fwd=image or None, tr=image or None)."""
+        n, k = w.shape
+        ent = dict(fwd=self.alloc(n, k, w.device) if fwd else None, tr=self.alloc(k, n, w.device) if tr else None)
+        if fwd:
+            self.items.append((w, ent["fwd"], False))
+        if tr:
+            self.items.append((w, ent["tr"], True))
+        return ent
+
+    def pack(self):
+        if self._ver != self.fp.version:
+            ops.pack_w16(self.items)
+            self._ver = self.fp.version
+
+
+def img_rows(img, r0, n):
+    """Rows r0 .. r0+n of a weight image as an image of its own (n rounded up to 64 rows, the spare rows belong to
+    the neighbouring slice or to the zero padding: their products land in columns that are never stored)."""
+    return img[r0:r0 + -(-n // 64) * 64]
+
+
 class Workspace:
     """Named device buffers, allocated on first use and reused while the shape is stable."""
 
@@ -212,7 +252,13 @@ class RnnStack:
         self.packed_b = [[torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.ndir)]
                          for _ in range(num_layers)]
         self.store = [torch.bfloat16 if (prec == BF16 and H % 2 == 0) else torch.float32 for layer in range(num_layers)]
-        self.w_gl = [torch.empty(self.ndir * 4 * H, self.in_p(layer), dtype=self.store[layer], device=dev)
+        # bf16 layers whose widths are multiples of 8 take the bf16-stored-operand products: their gate-interleaved
+        # W_ih image is padded the way ops.mm16_nt reads it (w_img; w_gl is its [rows, in_p] corner)
+        self.mm16 = [MM16 and self.store[layer] == torch.bfloat16 and H % 8 == 0 for layer in range(num_layers)]
+        self.w_img = [W16Images.alloc(self.ndir * 4 * H, self.in_p(layer), dev) if self.mm16[layer] else None
+                      for layer in range(num_layers)]
+        self.w_gl = [self.w_img[layer][:self.ndir * 4 * H] if self.mm16[layer] else
+                     torch.empty(self.ndir * 4 * H, self.in_p(layer), dtype=self.store[layer], device=dev)
                      for layer in range(num_layers)]
         self.bias_gl = [torch.empty(self.ndir * 4 * H, dtype=torch.float32, device=dev) for _ in range(num_layers)]
         self._ver_f = self._ver_b = -1
@@ -278,47 +324,101 @@ class RnnStack:
         self.pack(need_bwd=False)
 
     def _xproj(self, layer, x, w_gl, bias_gl, xproj):
-        if self.store[layer] == torch.bfloat16:
-            ops.linear_fwd_b16(x, w_gl, bias_gl, xproj)
+        """Input-side pre-activations from the rows ``w_gl`` of the layer's gate-interleaved weight image."""
+        if x.dtype == torch.bfloat16:
+            assert self.mm16[layer]
+            ops.mm16_nt(x, w_gl, bias_gl, xproj)
+        elif self.store[layer] == torch.bfloat16:
+            ops.linear_fwd_b16(x, w_gl[:xproj.shape[1], :x.shape[1]], bias_gl, xproj)
         else:
             ops.linear_fwd(self.prec, x, w_gl, bias_gl, xproj)
 
     def forward(self, x, B, T, ws: Workspace, tag, train):
+        """x [B*T, in_dim] float32, or bfloat16 where layer 0 takes the bf16-stored-operand products.  Returns the
+        float32 output of the last layer; ``self.out16`` holds the bfloat16 copies the sequence kernels wrote beside
+        (per layer, None where a layer wrote none)."""
         fp, H, nd, prec = self.fp, self.H, self.ndir, self.prec
         BT = B * T
         H4 = 4 * H
         lstm = self.cell == CELL_LSTM
         self._in = x
         self._B, self._T = B, T
+        self.out16 = [None] * self.L
         inp = x
         for layer in range(self.L):
             sdt = self.store[layer]
+            last = layer == self.L - 1
             xproj = ws.get(f"{tag}.xproj{layer}", (BT, nd * H4), dtype=sdt)
+            w = self.w_img[layer] if self.mm16[layer] else self.w_gl[layer]
             if self.mode == "bidir" or layer == 0:
-                self._xproj(layer, self._padded(layer, inp, ws, tag), self.w_gl[layer], self.bias_gl[layer], xproj)
+                xin = inp if inp.dtype == torch.bfloat16 else self._padded(layer, inp, ws, tag)
+                self._xproj(layer, xin, w, self.bias_gl[layer], xproj)
             else:
                 for d in range(nd):
                     sl = slice(d * H4, (d + 1) * H4)
                     assert self.in_p(layer) == self.in_l(layer)        # H even: no padding between heads
-                    self._xproj(layer, inp[:, d * H:(d + 1) * H], self.w_gl[layer][sl], self.bias_gl[layer][sl], xproj[:, sl])
-            out = ws.get(f"{tag}.out{layer}", (BT, nd * H))
+                    wd = img_rows(w, d * H4, H4) if self.mm16[layer] else w[sl]
+                    self._xproj(layer, inp[:, d * H:(d + 1) * H], wd, self.bias_gl[layer][sl], xproj[:, sl])
+            # h_t as bf16 for the products that read it (the next layer's input side, the weight gradients); as fp32
+            # where something else reads it: the consumer of the stack's result and the backward of a GRU (h_{t-1})
+            want16 = self.mm16[layer] and (train or (not last and self.mm16[layer + 1]))
+            want32 = last or not want16 or (train and not lstm) or (not last and not self.mm16[layer + 1])
+            out = ws.get(f"{tag}.out{layer}", (BT, nd * H)) if want32 else None
+            out16 = ws.get(f"{tag}.out16_{layer}", (BT, nd * H), dtype=torch.bfloat16) if want16 else None
+            self.out16[layer] = out16
             gates = ws.get(f"{tag}.gates{layer}", (BT, nd * H4), dtype=sdt) if train else None
             cst = ws.get(f"{tag}.c{layer}", (BT, nd * H)) if (train and lstm) else None
             dirs = []
             for d in range(nd):
                 sl = slice(d * H4, (d + 1) * H4)
+                hs = slice(d * H, (d + 1) * H)
                 dirs.append(dict(xproj=xproj[:, sl], w_packed=self.packed_f[layer][d],
                                  b_hh=fp.p(self.name("bias_hh", layer, d)) if not lstm else None,
-                                 out=out[:, d * H:(d + 1) * H], gates=gates[:, sl] if train else None,
-                                 cstate=cst[:, d * H:(d + 1) * H] if cst is not None else None, reverse=self.rev[d]))
+                                 out=out[:, hs] if out is not None else None,
+                                 out16=out16[:, hs] if out16 is not None else None, gates=gates[:, sl] if train else None,
+                                 cstate=cst[:, hs] if cst is not None else None, reverse=self.rev[d]))
             fp.release()
             ops.rnn_fwd(self.cell, prec, B, T, H, dirs)
-            inp = out
+            inp = out16 if (not last and self.mm16[layer + 1] and out16 is not None) else out
         return inp
 
     def _weight_grads(self, layer, dg, inp, out, gb_ih, gb_hh, in_map, hid_map):
         """Weight and bias gradients of one layer from its pre-activation gradients ``dg``."""
         fp, H, nd, prec, T = self.fp, self.H, self.ndir, self.prec, self._T
+        GH, H4 = self.G * H, 4 * H
+        lstm = self.cell == CELL_LSTM
+        shared = self.mode == "bidir" or layer == 0
+        if self.mm16[layer] and self.out16[layer] is not None:
+            # one launch: the input-side and both recurrent products read the pre-activation gradients once
+            jobs = []
+            if inp.dtype == torch.bfloat16 and inp.shape[1] == (self.in_l(layer) if shared else nd * H):
+                if shared:
+                    jobs.append(dict(b=inp, c=fp.ggroup(self.name("weight_ih", layer, 0), nd * GH, self.in_l(layer)), a0=0,
+                                     na=nd * H4, gate_map=in_map, db=gb_ih, db2=gb_hh if lstm else None))
+                else:
+                    for d in range(nd):
+                        sl = slice(d * GH, (d + 1) * GH)
+                        jobs.append(dict(b=inp[:, d * H:(d + 1) * H], c=fp.g(self.name("weight_ih", layer, d)), a0=d * H4, na=H4,
+                                         gate_map=in_map, db=gb_ih[sl], db2=gb_hh[sl] if lstm else None))
+            else:
+                self._weight_grads_in(layer, dg, inp, gb_ih, gb_hh, in_map)
+            o16 = self.out16[layer]
+            for d in range(nd):
+                jobs.append(dict(b=o16[:, d * H:(d + 1) * H], c=fp.g(self.name("weight_hh", layer, d)), a0=d * H4, na=H4,
+                                 shift=(1 if self.rev[d] else -1), gate_map=hid_map,
+                                 db=None if lstm else gb_hh[d * GH:(d + 1) * GH]))
+            ops.mm16_tn(dg, jobs, T=T)
+            return
+        self._weight_grads_in(layer, dg, inp, gb_ih, gb_hh, in_map)
+        # recurrent weights: dW_hh += dgates^T h_{t-1}
+        for d in range(nd):
+            ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], out[:, d * H:(d + 1) * H],
+                                  fp.g(self.name("weight_hh", layer, d)), db=None if lstm else gb_hh[d * GH:(d + 1) * GH],
+                                  T=T, tshift=(1 if self.rev[d] else -1), gate_map=hid_map)
+
+    def _weight_grads_in(self, layer, dg, inp, gb_ih, gb_hh, in_map):
+        """Input-side weight and bias gradients of one layer through the fp32-operand product."""
+        fp, H, nd, prec = self.fp, self.H, self.ndir, self.prec
         GH, H4 = self.G * H, 4 * H
         lstm = self.cell == CELL_LSTM
         if self.mode == "bidir" or layer == 0:
@@ -330,11 +430,6 @@ class RnnStack:
                 ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], inp[:, d * H:(d + 1) * H],
                                       fp.g(self.name("weight_ih", layer, d)), db=gb_ih[sl], db2=gb_hh[sl] if lstm else None,
                                       gate_map=in_map)
-        # recurrent weights: dW_hh += dgates^T h_{t-1}
-        for d in range(nd):
-            ops.linear_bwd_weight(prec, dg[:, d * H4:(d + 1) * H4], out[:, d * H:(d + 1) * H],
-                                  fp.g(self.name("weight_hh", layer, d)), db=None if lstm else gb_hh[d * GH:(d + 1) * GH],
-                                  T=T, tshift=(1 if self.rev[d] else -1), gate_map=hid_map)
 
     def backward(self, dout, ws: Workspace, tag, need_dx, relu_of=None):
         fp, H, G, nd, prec = self.fp, self.H, self.G, self.ndir, self.prec
@@ -346,10 +441,16 @@ class RnnStack:
         hid_map = (H, G, self.HID_SLOTS[self.cell])
         for layer in range(self.L - 1, -1, -1):
             sdt = self.store[layer]
-            out = ws.get(f"{tag}.out{layer}", (BT, nd * H))
+            out = ws.bufs.get(f"{tag}.out{layer}")          # fp32 h_t: absent where only bf16 copies were needed
+            assert lstm or out is not None
             gates = ws.get(f"{tag}.gates{layer}", (BT, nd * H4), dtype=sdt)
             cst = ws.get(f"{tag}.c{layer}", (BT, nd * H)) if lstm else None
-            inp = self._in if layer == 0 else ws.get(f"{tag}.out{layer - 1}", (BT, nd * H))
+            if layer == 0:
+                inp = self._in
+            elif self.mm16[layer] and self.out16[layer - 1] is not None:
+                inp = self.out16[layer - 1]
+            else:
+                inp = ws.bufs[f"{tag}.out{layer - 1}"]
             dg = ws.get(f"{tag}.dg{layer}", (BT, nd * H4), dtype=sdt)
             dirs = []
             for d in range(nd):
@@ -375,12 +476,13 @@ class RnnStack:
                 assert not (padded and ro is not None), "a ReLU mask on a padded layer input is not supported"
                 bwd_data = (lambda dy, w, o, r=None: ops.linear_bwd_data_b16(dy, w, o, relu_of=r)) if sdt == torch.bfloat16 else \
                     (lambda dy, w, o, r=None: ops.linear_bwd_data(prec, dy, w, o, relu_of=r))
+                wl = self.w_gl[layer][:, :self.in_p(layer)]
                 if shared:
-                    bwd_data(dg, self.w_gl[layer], dx, ro)
+                    bwd_data(dg, wl, dx, ro)
                 else:
                     for d in range(nd):
                         sl = slice(d * H4, (d + 1) * H4)
-                        bwd_data(dg[:, sl], self.w_gl[layer][sl], dx[:, d * H:(d + 1) * H])
+                        bwd_data(dg[:, sl], wl[sl], dx[:, d * H:(d + 1) * H])
                 dout = dx[:, :in_l] if padded else dx            # the pad columns meet zero weights: they hold zeros
             else:
                 dout = None
@@ -400,6 +502,7 @@ class EmbBlock:
         for c in self.cards[:-1]:
             self.tab_off.append(self.tab_off[-1] + c)
         self.cat_dim = self.nd * E + 16 * n_nums
+        self.mm16 = False
 
     @staticmethod
     def layout(prefix, n_disc, n_nums):
@@ -411,7 +514,26 @@ class EmbBlock:
                 (f"{prefix}mlp_output.2.weight", False), (f"{prefix}mlp_output.2.bias", False)]
         return out
 
-    def forward(self, x, ws: Workspace, tag):
+    def use_mm16(self, imgs):
+        """Switch the block to the bf16-stored-operand products (bf16 precision, widths that are multiples of 8):
+        registers its weight images with ``imgs`` (W16Images).  The last layer joins when its width allows."""
+        fp, pre = self.fp, self.prefix
+        if not (MM16 and self.prec == BF16 and self.E % 8 == 0):
+            return
+        self.imgs = imgs
+        self.last16 = fp.p(pre + "mlp_output.2.weight").shape[0] % 8 == 0
+        self.im = {}
+        if self.nn:
+            self.im["n0"] = imgs.add(fp.p(pre + "mlp_nums.0.weight"), fwd=True, tr=False)
+            self.im["n2"] = imgs.add(fp.p(pre + "mlp_nums.2.weight"), fwd=True, tr=True)
+        self.im["o0"] = imgs.add(fp.p(pre + "mlp_output.0.weight"), fwd=True, tr=True)
+        if self.last16:
+            self.im["o2"] = imgs.add(fp.p(pre + "mlp_output.2.weight"), fwd=True, tr=True)
+        self.mm16 = True
+
+    def forward(self, x, ws: Workspace, tag, want16=False):
+        if self.mm16:
+            return self._forward16(x, ws, tag, want16)
         fp, pre, E, prec, nd, nn = self.fp, self.prefix, self.E, self.prec, self.nd, self.nn
         rows = x.shape[0]
         self._x = x
@@ -434,7 +556,43 @@ class EmbBlock:
         ops.linear_fwd(prec, a2, w2, fp.p(pre + "mlp_output.2.bias"), out)
         return out
 
+    def _forward16(self, x, ws, tag, want16):
+        """The same launches with every tensor that only matrix products read kept as bfloat16 (the products round
+        their operands to bf16 anyway, so the values are those of the fp32-stored path); z1, which SiLU and its
+        derivative read, stays float32.  Returns bfloat16 if ``want16`` and the last layer's width allows."""
+        fp, pre, E, nd, nn, im = self.fp, self.prefix, self.E, self.nd, self.nn, self.im
+        rows = x.shape[0]
+        b16 = torch.bfloat16
+        self._x = x
+        self.imgs.pack()
+        ecat = ws.get(f"{tag}.ecat16", (rows, self.cat_dim), dtype=b16)
+        if nd:
+            tables = fp.pgroup(f"{pre}embeddings_list.0.weight", sum(self.cards), E)
+            ops.embed_fwd(x[:, :nd], tables, self.tab_off, self.cards, E, ecat[:, :nd * E])
+        if nn:
+            feats = ws.get(f"{tag}.feats16", (rows, 16 * nn), dtype=b16)
+            z1 = ws.get(f"{tag}.z1", (rows, 16 * nn))
+            a1 = ws.get(f"{tag}.a1_16", (rows, 16 * nn), dtype=b16)
+            ops.sincos_features(x[:, nd:nd + nn], feats)
+            ops.mm16_nt(feats, im["n0"]["fwd"], fp.p(pre + "mlp_nums.0.bias"), z1)
+            ops.silu_fwd(z1, a1)
+            ops.mm16_nt(a1, im["n2"]["fwd"], fp.p(pre + "mlp_nums.2.bias"), ecat[:, nd * E:])
+        w2 = fp.p(pre + "mlp_output.2.weight")
+        if self.last16:
+            a2 = ws.get(f"{tag}.a2_16", (rows, E), dtype=b16)
+            ops.mm16_nt(ecat, im["o0"]["fwd"], fp.p(pre + "mlp_output.0.bias"), a2, act=ACT_RELU)
+            out = ws.get(f"{tag}.out16" if want16 else f"{tag}.out", (rows, w2.shape[0]), dtype=b16 if want16 else torch.float32)
+            ops.mm16_nt(a2, im["o2"]["fwd"], fp.p(pre + "mlp_output.2.bias"), out)
+        else:
+            a2 = ws.get(f"{tag}.a2", (rows, E))
+            ops.mm16_nt(ecat, im["o0"]["fwd"], fp.p(pre + "mlp_output.0.bias"), a2, act=ACT_RELU)
+            out = ws.get(f"{tag}.out", (rows, w2.shape[0]))
+            ops.linear_fwd(self.prec, a2, w2, fp.p(pre + "mlp_output.2.bias"), out)
+        return out
+
     def backward(self, dout, ws: Workspace, tag):
+        if self.mm16:
+            return self._backward16(dout, ws, tag)
         fp, pre, E, prec, nd, nn = self.fp, self.prefix, self.E, self.prec, self.nd, self.nn
         rows = dout.shape[0]
         x = self._x
@@ -460,6 +618,50 @@ class EmbBlock:
             dz1 = ws.get(f"{tag}.dz1", (rows, 16 * nn))
             ops.silu_bwd(z1, da1, dz1)
             fp.defer(ops.linear_bwd_weight, prec, dz1, feats, fp.g(pre + "mlp_nums.0.weight"), db=fp.g(pre + "mlp_nums.0.bias"))
+
+    def _backward16(self, dout, ws, tag):
+        """dout: float32 or bfloat16 [rows, width of the block's result]."""
+        fp, pre, E, prec, nd, nn, im = self.fp, self.prefix, self.E, self.prec, self.nd, self.nn, self.im
+        rows = dout.shape[0]
+        b16 = torch.bfloat16
+        x = self._x
+        ecat = ws.get(f"{tag}.ecat16", (rows, self.cat_dim), dtype=b16)
+        da2 = ws.get(f"{tag}.da2_16", (rows, E), dtype=b16)
+        gw2, gb2 = fp.g(pre + "mlp_output.2.weight"), fp.g(pre + "mlp_output.2.bias")
+        if self.last16:
+            a2 = ws.get(f"{tag}.a2_16", (rows, E), dtype=b16)
+            if dout.dtype != b16:
+                d16 = ws.get(f"{tag}.dout16", tuple(dout.shape), dtype=b16)
+                ops.cvt_bf16(dout, d16)
+                dout = d16
+            ops.mm16_nt(dout, im["o2"]["tr"], None, da2, relu_of=a2)
+            fp.defer(ops.mm16_tn, dout, [dict(b=a2, c=gw2, db=gb2)])
+        else:
+            a2 = ws.get(f"{tag}.a2", (rows, E))
+            da2f = ws.get(f"{tag}.da2", (rows, E))
+            ops.linear_bwd_data(prec, dout, fp.p(pre + "mlp_output.2.weight"), da2f, relu_of=a2)
+            fp.defer(ops.linear_bwd_weight, prec, dout, a2, gw2, db=gb2)
+            ops.cvt_bf16(da2f, da2)
+        fp.defer(ops.mm16_tn, da2, [dict(b=ecat, c=fp.g(pre + "mlp_output.0.weight"), db=fp.g(pre + "mlp_output.0.bias"))])
+        wt = im["o0"]["tr"]                       # [cat_dim, E]: rows = columns of ecat
+        if nd:
+            # the table gradients sum these values element by element: float32
+            de = ws.get(f"{tag}.decat_d", (rows, nd * E))
+            ops.mm16_nt(da2, img_rows(wt, 0, nd * E), None, de)
+            gt = fp.ggroup(f"{pre}embeddings_list.0.weight", sum(self.cards), E)
+            fp.defer(ops.embed_bwd, x[:, :nd], de, gt, self.tab_off, self.cards, E)
+        if nn:
+            feats = ws.get(f"{tag}.feats16", (rows, 16 * nn), dtype=b16)
+            z1 = ws.get(f"{tag}.z1", (rows, 16 * nn))
+            a1 = ws.get(f"{tag}.a1_16", (rows, 16 * nn), dtype=b16)
+            dy1 = ws.get(f"{tag}.dy1_16", (rows, 16 * nn), dtype=b16)
+            ops.mm16_nt(da2, img_rows(wt, nd * E, 16 * nn), None, dy1)
+            da1 = ws.get(f"{tag}.da1", (rows, 16 * nn))
+            ops.mm16_nt(dy1, im["n2"]["tr"], None, da1)
+            fp.defer(ops.mm16_tn, dy1, [dict(b=a1, c=fp.g(pre + "mlp_nums.2.weight"), db=fp.g(pre + "mlp_nums.2.bias"))])
+            dz1 = ws.get(f"{tag}.dz1_16", (rows, 16 * nn), dtype=b16)
+            ops.silu_bwd(z1, da1, dz1)
+            fp.defer(ops.mm16_tn, dz1, [dict(b=feats, c=fp.g(pre + "mlp_nums.0.weight"), db=fp.g(pre + "mlp_nums.0.bias"))])
 
 
 def _lin_bwd(fp, prec, dy, x, w, gw, gb, dx=None, relu_of=None, accumulate=False):
@@ -499,6 +701,18 @@ class DenoiserEngine:
         self.lstm = RnnStack(self.fp, CELL_LSTM, self.H, self.H, self.L, lstm_dirs, "bidir", self.prec)
         self.gru = RnnStack(self.fp, CELL_GRU, self.H, self.E, self.L, gru_dirs, "bidir", self.prec)
         self.emb = EmbBlock(self.fp, "Emb.", nb, nc, nn, cards, self.E, self.prec)
+        self.imgs = W16Images(self.fp)
+        self.emb.use_mm16(self.imgs)
+        # the training step keeps what only matrix products read as bfloat16 when every width involved is a multiple of 8
+        self.mm16 = bool(MM16 and self.prec == BF16 and self.H % 8 == 0 and self.emb.mm16 and self.emb.last16
+                         and all(self.gru.mm16) and all(self.lstm.mm16))
+        if self.mm16:
+            p_ = self.fp.p
+            self.im = dict(co=self.imgs.add(p_("cond_output.weight"), fwd=True, tr=True),
+                           proj=self.imgs.add(p_("proj.net.0.weight"), fwd=True, tr=True),
+                           te2=self.imgs.add(p_("time_encode.2.weight"), fwd=True, tr=True))
+            if self.time_dim % 8 == 0:
+                self.im["te0"] = self.imgs.add(p_("time_encode.0.weight"), fwd=True, tr=False)
         self.ws = Workspace(device)
         self.scale_t = module.t_enc.scale.to(device=device, dtype=torch.float32).contiguous()
         self.shift_t = module.t_enc.shift.to(device=device, dtype=torch.float32).contiguous()
@@ -531,6 +745,9 @@ class DenoiserEngine:
         ti2 = time_info.reshape(BT, self.time_dim)
         c2 = cond.reshape(BT, self.F)
         self._saved = (x2, t1, i1, ti2, B, T)
+        self._fwd16 = self.mm16 and train
+        if self._fwd16:
+            return self._forward16(x2, t1, i1, ti2, c2, B, T)
         cat = ws.get("cat", (BT, 4 * H))
         ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), cat[:, :H])
         emb = self.emb.forward(c2, ws, "emb")
@@ -552,6 +769,52 @@ class DenoiserEngine:
         ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
         return pred.view(B, T, K)
 
+    def _forward16(self, x2, t1, i1, ti2, c2, B, T):
+        """The training forward with every tensor that only matrix products read kept as bfloat16: the products
+        round their operands to bf16 anyway, so a tensor stored rounded yields the same values as one stored in
+        float32.  What anything else reads stays float32: the input projection (summed with cond_output's result
+        before the one rounding of `proj`'s operand), the GRU's h_t (its backward), the LSTM's last h_t (LayerNorm)."""
+        fp, ws, prec, H, K, im = self.fp, self.ws, self.prec, self.H, self.K, self.im
+        BT = B * T
+        b16 = torch.bfloat16
+        self.imgs.pack()
+        xh = ws.get("xh", (BT, H))
+        ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
+        emb = self.emb.forward(c2, ws, "emb", want16=True)
+        fp.join()
+        cat = ws.get("cat16", (BT, 4 * H), dtype=b16)
+        ta = ws.get("ta16", (BT, H), dtype=b16)
+        fp.defer_until_release(self._encodings16, cat, ta, t1, i1, ti2, BT)
+        self.gru.forward(emb, B, T, ws, "gru", True)
+        gout16 = self.gru.out16[self.L - 1]
+        ops.mm16_nt(gout16, im["co"]["fwd"], fp.p("cond_output.bias"), cat[:, :H], residual=xh)
+        fp.join()
+        pa = ws.get("pa16", (BT, H), dtype=b16)
+        ops.mm16_nt(cat, im["proj"]["fwd"], fp.p("proj.net.0.bias"), pa, act=ACT_RELU)
+        lout = self.lstm.forward(pa, B, T, ws, "lstm", True)
+        ln = ws.get("ln", (BT, 2 * H))
+        mr = ws.get("mr", (BT, 2))
+        ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, mr)
+        pred = ws.get("pred", (BT, K))
+        ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
+        return pred.view(B, T, K)
+
+    def _encodings16(self, cat, ta, t1, i1, ti2, BT):
+        fp, ws, prec, H, im = self.fp, self.ws, self.prec, self.H, self.im
+        ops.posenc_fwd(t1, 1, BT, H, 1.0, fp.p("t_enc.linear_proj.weight"), fp.p("t_enc.linear_proj.bias"), self.scale_t,
+                       self.shift_t, cat[:, H:2 * H])
+        ops.posenc_fwd(i1, 1, BT, H, 1.0 / self.i_max, fp.p("i_enc.linear_proj.weight"), fp.p("i_enc.linear_proj.bias"),
+                       self.scale_i, self.shift_i, cat[:, 2 * H:3 * H])
+        if "te0" in im:
+            ti16 = ws.get("ti16", (BT, self.time_dim), dtype=torch.bfloat16)
+            ops.cvt_bf16(ti2, ti16)
+            ops.mm16_nt(ti16, im["te0"]["fwd"], fp.p("time_encode.0.bias"), ta, act=ACT_RELU)
+        else:
+            taf = ws.get("ta", (BT, H))
+            ops.linear_fwd(prec, ti2, fp.p("time_encode.0.weight"), fp.p("time_encode.0.bias"), taf, act=ACT_RELU)
+            ops.cvt_bf16(taf, ta)
+        ops.mm16_nt(ta, im["te2"]["fwd"], fp.p("time_encode.2.bias"), cat[:, 3 * H:])
+
     def _encodings(self, cat, ta, t1, i1, ti2, BT):
         """t_enc | i_enc | time_encode -> columns H..4H of the input of `proj` (reference DIFF.py:199-204)."""
         fp, prec, H = self.fp, self.prec, self.H
@@ -570,6 +833,8 @@ class DenoiserEngine:
         BT = B * T
         Lh = H // 2
         dpred = dpred.reshape(BT, K)
+        if self._fwd16:
+            return self._backward16(dpred)
         cat = ws.get("cat", (BT, 4 * H))
         ta = ws.get("ta", (BT, H))
         pa = ws.get("pa", (BT, H))
@@ -597,6 +862,53 @@ class DenoiserEngine:
         _lin_bwd(fp, prec, dta, ti2, None, fp.g("time_encode.0.weight"), fp.g("time_encode.0.bias"))
         dgout = ws.get("dgout", (BT, 2 * H))
         _lin_bwd(fp, prec, dxh, gout, fp.p("cond_output.weight"), fp.g("cond_output.weight"), fp.g("cond_output.bias"), dx=dgout)
+        demb = self.gru.backward(dgout, ws, "gru", need_dx=True)
+        self.emb.backward(demb, ws, "emb")
+        fp.join()
+
+    def _backward16(self, dpred):
+        fp, ws, prec, H, K, im = self.fp, self.ws, self.prec, self.H, self.K, self.im
+        x2, t1, i1, ti2, B, T = self._saved
+        BT = B * T
+        Lh = H // 2
+        b16 = torch.bfloat16
+        cat = ws.get("cat16", (BT, 4 * H), dtype=b16)
+        ta = ws.get("ta16", (BT, H), dtype=b16)
+        pa = ws.get("pa16", (BT, H), dtype=b16)
+        ln = ws.get("ln", (BT, 2 * H))
+        mr = ws.get("mr", (BT, 2))
+        lout = ws.get("lstm.out%d" % (self.L - 1), (BT, 2 * H))
+        gout16 = self.gru.out16[self.L - 1]
+        dln = ws.get("dln", (BT, 2 * H))
+        _lin_bwd(fp, prec, dpred, ln, fp.p("fc.weight"), fp.g("fc.weight"), fp.g("fc.bias"), dx=dln)
+        dlout = ws.get("dlout", (BT, 2 * H))
+        ops.layernorm_bwd(dln, lout, fp.p("layer_norm.weight"), mr, dlout, fp.g("layer_norm.weight"), fp.g("layer_norm.bias"))
+        dpa = self.lstm.backward(dlout, ws, "lstm", need_dx=True)
+        dpz = ws.get("dpz16", (BT, H), dtype=b16)
+        ops.cvt_bf16(dpa, dpz, relu_of=pa)                                  # the ReLU of proj
+        fp.defer(ops.mm16_tn, dpz, [dict(b=cat, c=fp.g("proj.net.0.weight"), db=fp.g("proj.net.0.bias"))])
+        # d(cat) in three pieces of proj's transposed image: the input-projection / cond_output share and the
+        # time-encoding share feed matrix products only (bf16); the t / step encodings' share is summed column by
+        # column (their weight and bias gradients): float32
+        wt = im["proj"]["tr"]
+        dxh = ws.get("dxh16", (BT, H), dtype=b16)
+        ops.mm16_nt(dpz, img_rows(wt, 0, H), None, dxh)
+        denc = ws.get("denc", (BT, 2 * H))
+        ops.mm16_nt(dpz, img_rows(wt, H, 2 * H), None, denc)
+        dtenc = ws.get("dtenc16", (BT, H), dtype=b16)
+        ops.mm16_nt(dpz, img_rows(wt, 3 * H, H), None, dtenc)
+        fp.defer(ops.linear_bwd_weight, prec, dxh, x2, fp.g("input_proj.net.0.weight"), db=fp.g("input_proj.net.0.bias"))
+        fp.defer(ops.colsum, denc[:, :Lh], out_sum=fp.g("t_enc.linear_proj.bias"), row_scale=t1, scale_mul=1.0,
+                 out_wsum=fp.g("t_enc.linear_proj.weight"))
+        fp.defer(ops.colsum, denc[:, H:H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
+                 out_wsum=fp.g("i_enc.linear_proj.weight"))
+        dta = ws.get("dta16", (BT, H), dtype=b16)
+        ops.mm16_nt(dtenc, im["te2"]["tr"], None, dta, relu_of=ta)
+        fp.defer(ops.mm16_tn, dtenc, [dict(b=ta, c=fp.g("time_encode.2.weight"), db=fp.g("time_encode.2.bias"))])
+        fp.defer(ops.linear_bwd_weight, prec, dta, ti2, fp.g("time_encode.0.weight"), db=fp.g("time_encode.0.bias"))
+        dgout = ws.get("dgout", (BT, 2 * H))
+        ops.mm16_nt(dxh, im["co"]["tr"], None, dgout)
+        fp.defer(ops.mm16_tn, dxh, [dict(b=gout16, c=fp.g("cond_output.weight"), db=fp.g("cond_output.bias"))])
         demb = self.gru.backward(dgout, ws, "gru", need_dx=True)
         self.emb.backward(demb, ws, "emb")
         fp.join()

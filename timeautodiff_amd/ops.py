@@ -209,6 +209,12 @@ def _dt(t):
     return BF16 if t.dtype == torch.bfloat16 else F32
 
 
+def _sfx(out):
+    """Entry-point suffix by the element type of a result: '' float32, '_b16' bfloat16."""
+    assert out.dtype in (torch.float32, torch.bfloat16), out.dtype
+    return "_b16" if out.dtype == torch.bfloat16 else ""
+
+
 def w16_image(n, k, device):
     """Zeroed storage of a padded bf16 weight image for mm16_nt: [n rounded up to 64, k rounded up to 128]."""
     return torch.zeros(-(-n // 64) * 64, -(-k // 128) * 128, dtype=torch.bfloat16, device=device)
@@ -270,6 +276,31 @@ def mm16_tn(a16, jobs, T=0):
     _call("tad_mm16_tn", M, T, ap, lda, len(jobs), arr, _stream(), cost=(flops, bytes_))
 
 
+def cvt_bf16(src, dst16, relu_of=None):
+    """dst16 (bfloat16) = src (float32), zero where relu_of (bfloat16) <= 0; all [rows, cols] row-strided views."""
+    sp, rows, cols, lds = as2d(src)
+    dp, rd, cd, ldd = as2d(dst16, torch.bfloat16)
+    assert rows == rd and cols == cd, (src.shape, dst16.shape)
+    mp, ldm = None, 0
+    if relu_of is not None:
+        mp, rm, cm, ldm = as2d(relu_of, torch.bfloat16)
+        assert rm == rows and cm == cols
+    _call("tad_cvt_bf16", rows, cols, sp, lds, dp, ldd, mp, ldm, _stream(), cost=(0.0, (6.0 + 2.0 * (mp is not None)) * rows * cols))
+
+
+def pack_w16(jobs):
+    """jobs: list of (w float32 [n, k] view, image bfloat16 2-d, transpose): image[:n, :k] = w (or image[:k, :n] = w^T)."""
+    if not jobs:
+        return
+    arr = (_lib.PackW16Job * len(jobs))()
+    for i, (w, img, tr) in enumerate(jobs):
+        wp, n, k, ldw = as2d(w)
+        ip, ir, ic, ldi = as2d(img, torch.bfloat16)
+        assert (ir >= k and ic >= n) if tr else (ir >= n and ic >= k), (w.shape, img.shape, tr)
+        arr[i] = _lib.PackW16Job(wp, ldw, n, k, ip, ldi, int(bool(tr)), 0)
+    _call("tad_pack_w16", len(jobs), arr, _stream())
+
+
 def colsum(dy, out_sum=None, out_sum2=None, row_scale=None, row_scale_stride=1, scale_mul=1.0, out_wsum=None):
     dyp, M, N, ldy = as2d(dy)
     _call("tad_colsum", M, N, dyp, ldy, _ptr(row_scale), row_scale_stride, float(scale_mul), _ptr(out_sum), _ptr(out_sum2),
@@ -313,17 +344,23 @@ def rnn_fwd(cell, prec, B, T, H, dirs):
         dt = d["xproj"].dtype
         assert _store_of(d["xproj"]) == store
         xp, _, _, ldxp = as2d(d["xproj"], dt)
-        op, _, _, ldo = as2d(d["out"])
+        op, ldo, o16, ldo16 = None, 0, None, 0
+        if d.get("out") is not None:
+            op, _, _, ldo = as2d(d["out"])
+        if d.get("out16") is not None:
+            o16, _, _, ldo16 = as2d(d["out16"], torch.bfloat16)
+        assert op is not None or o16 is not None
         gp, ldg, cp, ldc = None, 0, None, 0
         if d.get("gates") is not None:
             gp, _, _, ldg = as2d(d["gates"], dt)
             if d.get("cstate") is not None:
                 cp, _, _, ldc = as2d(d["cstate"])
         arr[k] = RnnDir(xp, ldxp, d["w_packed"].data_ptr(), _ptr(d.get("b_hh")), op, ldo, gp, ldg, cp, ldc,
-                        int(d["reverse"]), 0)
+                        int(d["reverse"]), 0, o16, ldo16)
     G, nd, esz = (4 if cell == CELL_LSTM else 3), len(dirs), dirs[0]["xproj"].element_size()
     train = dirs[0].get("gates") is not None
-    per_elem = 4 * esz + 4 + ((4 * esz + (4 if cell == CELL_LSTM else 0)) if train else 0)     # xproj in, h out, stash out
+    h_bytes = (4 if dirs[0].get("out") is not None else 0) + (2 if dirs[0].get("out16") is not None else 0)
+    per_elem = 4 * esz + h_bytes + ((4 * esz + (4 if cell == CELL_LSTM else 0)) if train else 0)     # xproj in, h out, stash out
     _call("tad_rnn_fwd", cell, prec, store, B, T, H, nd, arr, _stream(),
           cost=(2.0 * B * T * nd * G * H * H, float(B * T * nd * H * per_elem)))
 
@@ -373,9 +410,9 @@ def mse_loss(pred, target, grad_scale, dpred, loss_sum):
 
 def sincos_features(x_nums, out):
     xp, rows, n, ldx = as2d(x_nums)
-    op, rows2, cols, ldo = as2d(out)
+    op, rows2, cols, ldo = as2d(out, out.dtype)
     assert rows == rows2 and cols == 16 * n
-    _call("tad_sincos_features", rows, n, xp, ldx, op, ldo, _stream())
+    _call("tad_sincos_features" + _sfx(out), rows, n, xp, ldx, op, ldo, _stream())
 
 
 def _i32(lst):
@@ -384,9 +421,9 @@ def _i32(lst):
 
 def embed_fwd(x_disc, tables, tab_off, cards, E, out):
     xp, rows, nd, ldx = as2d(x_disc)
-    op, rows2, cols, ldo = as2d(out)
+    op, rows2, cols, ldo = as2d(out, out.dtype)
     assert rows == rows2 and cols == nd * E and len(cards) == nd
-    _call("tad_embed_fwd", rows, nd, E, xp, ldx, tables.data_ptr(), _i32(tab_off), _i32(cards), op, ldo, _stream())
+    _call("tad_embed_fwd" + _sfx(out), rows, nd, E, xp, ldx, tables.data_ptr(), _i32(tab_off), _i32(cards), op, ldo, _stream())
 
 
 def embed_bwd(x_disc, dout, dtables, tab_off, cards, E):
@@ -397,20 +434,20 @@ def embed_bwd(x_disc, dout, dtables, tab_off, cards, E):
 
 
 def posenc_fwd(t, t_stride, rows, H, inv_max, w, b, scale, shift, out):
-    op, rows2, cols, ldo = as2d(out)
+    op, rows2, cols, ldo = as2d(out, out.dtype)
     assert rows == rows2 and cols == H
-    _call("tad_posenc_fwd", rows, H, t.data_ptr(), t_stride, float(inv_max), w.data_ptr(), b.data_ptr(), scale.data_ptr(),
+    _call("tad_posenc_fwd" + _sfx(out), rows, H, t.data_ptr(), t_stride, float(inv_max), w.data_ptr(), b.data_ptr(), scale.data_ptr(),
           shift.data_ptr(), op, ldo, _stream())
 
 
 def silu_fwd(z, a):
     assert z.is_contiguous() and a.is_contiguous()
-    _call("tad_silu_fwd", z.numel(), z.data_ptr(), a.data_ptr(), _stream())
+    _call("tad_silu_fwd" + _sfx(a), z.numel(), z.data_ptr(), a.data_ptr(), _stream())
 
 
 def silu_bwd(z, da, dz):
     assert z.is_contiguous() and da.is_contiguous() and dz.is_contiguous()
-    _call("tad_silu_bwd", z.numel(), z.data_ptr(), da.data_ptr(), dz.data_ptr(), _stream())
+    _call("tad_silu_bwd" + _sfx(dz), z.numel(), z.data_ptr(), da.data_ptr(), dz.data_ptr(), _stream())
 
 
 def layernorm_fwd(x, gamma, beta, y, mean_rstd, eps=1e-5):
