@@ -1,0 +1,91 @@
+"""Device handling and argument guards of the Python layer (GPU): the engine is keyed by an indexed device, operands
+on a device that is not current are rejected before any launch, short data tables raise the reference's IndexError,
+and an optimizer step leaves parameters that received no gradient untouched."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _denoiser(H=24, E=16):
+    from timeautodiff_amd import DIFF
+    torch.manual_seed(3)
+    return DIFF.BiRNN_score(6, 6, H, 2, 100, 8, E, 0, 0, 6, [])
+
+
+def test_engine_is_not_rebuilt_for_an_equivalent_device_name():
+    m = _denoiser()
+    e0 = m.engine("cuda")
+    assert e0.device == torch.device("cuda", torch.cuda.current_device())
+    assert m.engine("cuda:0") is e0 and m.engine(torch.device("cuda")) is e0 and m.engine() is e0
+    x = torch.randn(2, 8, 6, device="cuda:0")
+    t = torch.rand(2, 8, 1, device="cuda:0").sort(1)[0]
+    i = torch.full((2, 8, 1), 3.0, device="cuda:0")
+    m(x, t, i, torch.randn(2, 8, 8, device="cuda:0"), torch.rand(2, 8, 6, device="cuda:0"))
+    assert m.engine() is e0                       # a forward on cuda:0 tensors keeps the engine built for "cuda"
+
+
+def test_cpu_operands_are_rejected_before_any_launch():
+    from timeautodiff_amd import _lib, ops
+    a = torch.zeros(4, 8)
+    with pytest.raises(_lib.TadError):
+        ops.silu_fwd(a, torch.zeros(4, 8, device="cuda"))
+
+
+def test_trainer_rejects_tables_shorter_than_the_latent():
+    from timeautodiff_amd import DIFF
+    m = _denoiser()
+    lat = torch.randn(10, 8, 6)
+    with pytest.raises(IndexError):
+        DIFF.DiffusionTrainer(m, lat, torch.randn(9, 8, 8), torch.rand(10, 8, 6), batch_size=4, dev="cuda")
+    with pytest.raises(ValueError):
+        DIFF.DiffusionTrainer(m, lat, torch.randn(10, 7, 8), torch.rand(10, 8, 6), batch_size=4, dev="cuda")
+
+
+def test_vae_step_without_cond_leaves_the_conditioning_branch_untouched():
+    """torch.optim.Adam skips parameters whose grad is None, weight decay included (reference VAE.py:315, 337-345
+    with cond None): Emb_decoder.* and Emb_hidden_decoder.* must not decay."""
+    from timeautodiff_amd import VAE
+    torch.manual_seed(5)
+    F, T = 6, 8
+    ae = VAE.DeapStack(1, 0, 0, F, [], F, 24, 2, 16, 8, 6)
+    before = {k: v.detach().cpu().clone() for k, v in ae.state_dict().items()}
+    x = torch.rand(12, T, F)
+    ones = torch.ones(12, T, F)
+    dd = dict(response_train=x, target_mask_train=ones, cond_train=None, response_val=x[:4], target_mask_val=ones[:4], cond_val=None)
+    tr = VAE.VAETrainer(ae, dd, batch_size=6, lr=1e-2, weight_decay=0.1, dtype="fp32", dev="cuda")
+    import random
+    random.seed(0)
+    for _ in range(3):
+        tr.train_step(0.1)
+    torch.cuda.synchronize()
+    after = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
+    moved = [k for k in before if not torch.equal(before[k], after[k])]
+    assert any(k.startswith("fc_mu") for k in moved)
+    frozen = [k for k in before if k.startswith("Emb_decoder.") or k.startswith("Emb_hidden_decoder.")]
+    assert frozen and all(torch.equal(before[k], after[k]) for k in frozen)
+
+
+def test_vae_bf16_with_a_hidden_size_that_is_not_a_multiple_of_8():
+    """H = 100, two layers: heads-mode layers slice their input per head at multiples of H, which bf16 rows cannot
+    do; the stack falls back to fp32 storage for its per-step tensors and must simply work."""
+    from timeautodiff_amd import VAE
+    torch.manual_seed(6)
+    F, T = 6, 8
+    ae = VAE.DeapStack(1, 0, 0, F, [], F, 100, 2, 16, 8, 6)
+    ae.set_compute_dtype("bf16")
+    x = torch.rand(5, T, F, device="cuda")
+    out = ae(x, torch.ones_like(x))
+    torch.cuda.synchronize()
+    leaves = out[0]["nums"] if isinstance(out, tuple) else out["nums"]
+    assert torch.isfinite(leaves).all()
+
+
+def test_empty_shard_is_a_no_op_for_the_sequence_kernels():
+    from timeautodiff_amd import _lib
+    lib = _lib.load()
+    dirs = (_lib.RnnDir * 1)()
+    assert lib.tad_rnn_fwd(0, 0, 0, 0, 8, 24, 1, dirs, None) == 0
+    bd = (_lib.RnnBwdDir * 1)()
+    assert lib.tad_rnn_bwd(0, 0, 0, 0, 8, 24, 1, bd, None) == 0

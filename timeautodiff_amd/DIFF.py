@@ -115,6 +115,8 @@ class BiRNN_score(nn.Module):
 
     def engine(self, dev=None) -> DenoiserEngine:
         dev = torch.device(dev) if dev is not None else (self._eng.device if self._eng is not None else device)
+        if dev.type == "cuda":
+            dev = ops.norm_device(dev)              # 'cuda' and 'cuda:0' name the same engine
         if dev.type != "cuda":
             raise RuntimeError("BiRNN_score runs only on an MI355X through libtad_hip.so; no GPU is visible "
                                "(there is no CPU fallback)")
@@ -127,6 +129,7 @@ class BiRNN_score(nn.Module):
         if self._eng is not None:
             self._eng.fp.version += 1
 
+    @ops.device_scope(lambda self, x, *a, **k: ops._first_cuda(x, self))
     def forward(self, x, t, i, time_info=None, cond=None, target_mask=None):
         if time_info is None or cond is None:
             raise NotImplementedError("time_info and cond are required (every reference driver passes both)")
@@ -168,6 +171,7 @@ def add_noise(x, t, i, *, noise=None):
     return xn, noise
 
 
+@ops.device_scope(lambda model, x, *a, **k: ops._first_cuda(x, model))
 def get_loss(model, x, t, time_info, cond=None, target_mask=None, *, i=None, noise=None):
     """reference DIFF.py:252-260 (forward only; the training loop uses the fused
     loss+backward of the engine).  Returns a 0-dim device tensor."""
@@ -208,6 +212,7 @@ class DiffusionTrainer:
     """One-GPU-per-process training state of the denoiser: device-resident dataset, flat
     parameters/gradients/Adam moments, per-step draws, optional data-parallel plan."""
 
+    @ops.device_scope(lambda self, model, *a, **k: k.get("dev") if k.get("dev") is not None else ops._first_cuda(model))
     def __init__(self, model: BiRNN_score, latent, time_info, cond, *, batch_size=None, lr=1e-3, dtype="fp32",
                  process_group=None, draws="reference", dev=None):
         model.set_compute_dtype(dtype)
@@ -220,6 +225,13 @@ class DiffusionTrainer:
         self.time_info = _stage(time_info, d)
         self.cond = _stage(cond, d)
         self.N, self.T, self.K = self.x.shape
+        # the batch gathers index all three with the same window numbers, unchecked on the device: a shorter
+        # time_info / cond would be read out of bounds where the reference raises IndexError (DIFF.py:309-311)
+        for nm, a in (("time_info", self.time_info), ("cond", self.cond)):
+            if len(a) < self.N:
+                raise IndexError(f"{nm} holds {len(a)} windows, latent {self.N}: index out of range")
+            if a.shape[1] != self.T:
+                raise ValueError(f"{nm} has T = {a.shape[1]}, latent T = {self.T}")
         self.B = batch_size if batch_size is not None else model.cfg["diffusion_steps"]
         self.lr = lr
         self.plan = DataParallelPlan(self.B, process_group)
@@ -240,6 +252,7 @@ class DiffusionTrainer:
         self.bt = ws.get("batch.time_info", (nb, self.T, self.time_info.shape[2]))
         self.bc = ws.get("batch.cond", (nb, self.T, self.cond.shape[2]))
 
+    @ops.device_scope(lambda self, *a, **k: self.eng.device)
     def draw(self):
         """The random draws of one iteration for the GLOBAL batch, in the reference's order
         (DIFF.py:306, 317, 253, 108): indices, t, i, noise."""
@@ -259,6 +272,7 @@ class DiffusionTrainer:
             noise = torch.randn(B, T, K, device=d, generator=self.gen)
         return dict(idx=idx, t=t, i=i, noise=noise)
 
+    @ops.device_scope(lambda self, *a, **k: self.eng.device)
     def step(self, draw=None, loss_out=None):
         """One optimizer step (reference DIFF.py:306-325).  ``loss_out`` (1-element device
         tensor view) receives the mean loss of the global batch without a host sync."""
@@ -325,6 +339,7 @@ def train_diffusion(latent_features, cond_df, data_dict, hidden_dim, num_layers,
 
 # ---------------------------------------------------------------------------
 @torch.no_grad()
+@ops.device_scope(lambda t, B, T, F, diffusion_steps, model, *a, **k: ops._first_cuda(model, t))
 def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, noise=None, dtype=None,
            process_group=None, noise_source="reference", keep=None, streams=None, graph=None):
     """reference DIFF.py:333-352: x_T ~ N(0,I), then 100 reverse steps with the step-0 double

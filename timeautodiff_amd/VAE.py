@@ -58,6 +58,8 @@ class DeapStack(nn.Module):
 
     def engine(self, dev=None) -> VAEEngine:
         dev = torch.device(dev) if dev is not None else (self._eng.device if self._eng is not None else device)
+        if dev.type == "cuda":
+            dev = ops.norm_device(dev)              # 'cuda' and 'cuda:0' name the same engine
         if dev.type != "cuda":
             raise RuntimeError("DeapStack runs only on an MI355X through libtad_hip.so; no GPU is visible "
                                "(there is no CPU fallback)")
@@ -73,6 +75,7 @@ class DeapStack(nn.Module):
         return a.to(device=eng.device, dtype=torch.float32).contiguous()
 
     # -- reference API ------------------------------------------------------
+    @ops.device_scope(lambda self, x, *a, **k: ops._first_cuda(x, self))
     def encoder(self, x, *, eps=None):
         """reference VAE.py:152-160 -> (emb, mu_z, logvar_z); the reparametrisation noise is drawn
         with torch.randn_like on the device unless ``eps`` is given."""
@@ -85,6 +88,7 @@ class DeapStack(nn.Module):
         z, mu, lv = eng.encoder(x, self._dev_f32(eps, eng), train=False)
         return z.clone(), mu.clone(), lv.clone()
 
+    @ops.device_scope(lambda self, x, *a, **k: ops._first_cuda(x, self))
     def decoder(self, latent_feature, mask=None, cond=None):
         """reference VAE.py:193-215 -> dict with 'bins' / 'cats' / 'nums' (present when that
         column type exists)."""
@@ -95,6 +99,7 @@ class DeapStack(nn.Module):
         heads = eng.decoder(z, self._dev_f32(mask, eng), self._dev_f32(cond, eng) if cond is not None else None)
         return eng.split_heads(heads, B, T)
 
+    @ops.device_scope(lambda self, x, *a, **k: ops._first_cuda(x, self))
     def decode_to_tensor(self, latent_feature, mask=None, cond=None):
         """decoder (VAE.py:193-215) followed by convert_to_tensor (process_edited.py:252-301) -- what every
         driver does with sampled latents -- without materialising the dict: [B,T,F] float32 of thresholded
@@ -108,6 +113,7 @@ class DeapStack(nn.Module):
         ops.heads_to_tensor(heads, eng.nb, eng.nc, eng.nn, eng.cards, out.view(B * T, eng.F))
         return out
 
+    @ops.device_scope(lambda self, x, *a, **k: ops._first_cuda(x, self))
     def forward(self, x, mask, cond=None, *, eps=None):
         emb, mu_z, logvar_z = self.encoder(x, eps=eps)
         outputs = self.decoder(emb, mask, cond)
@@ -165,6 +171,7 @@ def auto_loss(inputs, reconstruction, n_bins, n_nums, n_cats, cards):
 class VAETrainer:
     """Device-resident training state of the VAE (one process per GPU)."""
 
+    @ops.device_scope(lambda self, ae, *a, **k: k.get("dev") if k.get("dev") is not None else ops._first_cuda(ae))
     def __init__(self, ae: DeapStack, data_dict, *, batch_size, lr, weight_decay, dtype="fp32", process_group=None, dev=None):
         ae.set_compute_dtype(dtype)
         self.ae = ae
@@ -204,6 +211,7 @@ class VAETrainer:
         total, _ = self.eng.total_loss(p[:2 + nc], p[2 + max(nc, 1)], beta, rows)
         return total
 
+    @ops.device_scope(lambda self, *a, **k: self.eng.device)
     def train_step(self, beta, idx=None, eps=None, prefetch=True):
         """One optimizer step (reference VAE.py:322-354) -> train loss (python float).  With idx=None the
         minibatch comes from ``random.sample`` like the reference's; prefetch=False on the last step of a run keeps
@@ -236,7 +244,7 @@ class VAETrainer:
                     train=True)
         eng.backward(beta, rows)
         plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.parts)
-        eng.fp.adam(self.lr, weight_decay=self.wd)
+        eng.fp.adam(self.lr, weight_decay=self.wd, upto=None if self.cond_tr is not None else eng.n_without_cond)
         if own_draw and prefetch:
             # the next minibatch's indices (python `random`, the reference's generator for them, VAE.py:340) are
             # drawn now, while the device works on this step: reading the loss back below blocks the host
@@ -248,6 +256,7 @@ class VAETrainer:
         idx = random.sample(self.all_indices, self.B)
         return torch.as_tensor(idx[self.plan.lo:self.plan.hi], dtype=torch.int64).to(self.eng.device)
 
+    @ops.device_scope(lambda self, *a, **k: self.eng.device)
     def eval_loss(self, beta, eps=None):
         """Full validation-set loss under the current weights (reference VAE.py:357-368)."""
         eng, plan = self.eng, self.vplan
@@ -265,6 +274,7 @@ class VAETrainer:
         plan.all_reduce(self.parts)
         return self._loss(self.Nv * self.T, beta)
 
+    @ops.device_scope(lambda self, *a, **k: self.eng.device)
     def full_forward(self, eps=None):
         """Forward of the whole training set (reference VAE.py:395-402) -> (output dict, latent)."""
         eng = self.eng

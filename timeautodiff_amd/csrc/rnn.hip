@@ -194,6 +194,7 @@ struct RnnFwdArgs {
   tad_rnn_dir_t d[MAXDIR];
   int B, T, H, NJ, nk, lds_ld, rpw;
   int kl;      // leading k-blocks of every chunk's W_hh image kept in LDS for the whole sequence
+  int out16_rows;   // 1: the bf16 copy of h_t is written from the LDS tile in 16-byte pieces (bf16 precision, aligned rows)
 };
 
 template <int CELL, bool BF16, bool ST16, int JPW>
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
           lds_put<BF16>(nxt, a.lds_ld, row, u, h);
           if (ok) {
             if (d.out) (d.out + (b0 + cr) * (int64_t)T * d.ld_out)[ooff] = h;
-            if (d.out16) (reinterpret_cast<bf16_t*>(d.out16) + (b0 + cr) * (int64_t)T * d.ld_out16)[o16off] = (bf16_t)h;
+            if (d.out16 && !(BF16 && a.out16_rows)) (reinterpret_cast<bf16_t*>(d.out16) + (b0 + cr) * (int64_t)T * d.ld_out16)[o16off] = (bf16_t)h;
             if (d.gates) {
               unsigned char* gp = reinterpret_cast<unsigned char*>(d.gates) + (b0 + cr) * (int64_t)T * d.ld_gates * SL::ESZ;
               *reinterpret_cast<raw_t*>(gp + goff) = sv;
@@ -365,6 +366,21 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
     RSTAMP(q4);
     __syncthreads();
     RSTAMP(q5);
+    if constexpr (BF16) {
+      // h_t sits in the LDS tile as bf16 (the next step's matrix operand): its copy for the products that read h
+      // leaves from there, 16 bytes per lane along a row, instead of 2 bytes per lane from the gate math
+      if (a.out16_rows && d.out16) {
+        const int cpr = H >> 3;                                    // 16-byte pieces per row
+        const int total = a.rpw * cpr;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+          const int row = i / cpr, ch = i - row * cpr;
+          if (b0 + row < a.B) {
+            const uint4 v = *reinterpret_cast<const uint4*>(nxt + ((size_t)row * a.lds_ld + 8 * ch) * 2);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(d.out16) + ((b0 + row) * (int64_t)T + tt) * d.ld_out16 + 8 * ch) = v;
+          }
+        }
+      }
+    }
 #ifdef EXP_STAMPS
     sSeed += q1 - q0; sMma += q2 - q1; sPre += q3 - q2; sGate += q4 - q3; sBar += q5 - q4;
 #endif
@@ -701,8 +717,9 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   TAD_CHECK(cell == TAD_CELL_LSTM || cell == TAD_CELL_GRU, "tad_rnn_fwd: bad cell %d", cell);
   TAD_CHECK(prec == TAD_F32 || prec == TAD_BF16, "tad_rnn_fwd: bad prec %d", prec);
   TAD_CHECK(store == TAD_F32 || (store == TAD_BF16 && prec == TAD_BF16), "tad_rnn_fwd: bad store %d (bf16 storage needs prec = TAD_BF16)", store);
-  TAD_CHECK(B > 0 && T > 0 && H > 0 && H <= 1024 && (ndir == 1 || ndir == 2) && dirs, "tad_rnn_fwd: bad shape B=%ld T=%ld H=%ld ndir=%d",
+  TAD_CHECK(B >= 0 && T > 0 && H > 0 && H <= 1024 && (ndir == 1 || ndir == 2) && dirs, "tad_rnn_fwd: bad shape B=%ld T=%ld H=%ld ndir=%d",
             (long)B, (long)T, (long)H, ndir);
+  if (B == 0) return TAD_OK;                   // an empty shard of a batch: nothing to do
   const int G = cell == TAD_CELL_LSTM ? 4 : 3;
   const bool bf = prec == TAD_BF16, st16 = store == TAD_BF16;
   const Geom g = geom(prec, H, G);
@@ -720,6 +737,9 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   a.B = (int)B; a.T = (int)T; a.H = (int)H; a.NJ = g.NJ; a.nk = g.nkf;
   a.rpw = rows_per_wg(B, ndir);
   a.lds_ld = g.width + (bf ? 8 : 4);
+  a.out16_rows = bf && H % 8 == 0 && a.lds_ld % 8 == 0;
+  for (int i = 0; i < ndir; ++i)
+    if (dirs[i].out16 && (dirs[i].ld_out16 % 8 != 0 || (reinterpret_cast<uintptr_t>(dirs[i].out16) & 15) != 0)) a.out16_rows = 0;
   size_t lds = (size_t)2 * 32 * a.lds_ld * (bf ? 2 : 4);
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_fwd: H=%ld needs %zu bytes of LDS in this precision (limit %zu)", (long)H, lds, LDS_LIMIT);
   a.kl = 0;
@@ -747,8 +767,9 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, 
   TAD_CHECK(cell == TAD_CELL_LSTM || cell == TAD_CELL_GRU, "tad_rnn_bwd: bad cell %d", cell);
   TAD_CHECK(prec == TAD_F32 || prec == TAD_BF16, "tad_rnn_bwd: bad prec %d", prec);
   TAD_CHECK(store == TAD_F32 || (store == TAD_BF16 && prec == TAD_BF16), "tad_rnn_bwd: bad store %d (bf16 storage needs prec = TAD_BF16)", store);
-  TAD_CHECK(B > 0 && T > 0 && H > 0 && H <= 1024 && (ndir == 1 || ndir == 2) && dirs, "tad_rnn_bwd: bad shape B=%ld T=%ld H=%ld ndir=%d",
+  TAD_CHECK(B >= 0 && T > 0 && H > 0 && H <= 1024 && (ndir == 1 || ndir == 2) && dirs, "tad_rnn_bwd: bad shape B=%ld T=%ld H=%ld ndir=%d",
             (long)B, (long)T, (long)H, ndir);
+  if (B == 0) return TAD_OK;
   const int G = cell == TAD_CELL_LSTM ? 4 : 3;
   const bool bf = prec == TAD_BF16, st16 = store == TAD_BF16;
   const Geom g = geom(prec, H, G);

@@ -156,10 +156,12 @@ class FlatParams:
             torch.cuda.current_stream().wait_event(self._join_ev)
             self._side_busy = False
 
-    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, upto=None):
+        """One Adam step over the active range, or over its first ``upto`` elements (the rest holds parameters
+        that received no gradient in this step: torch.optim.Adam skips those, weight decay included)."""
         self.step += 1
-        ops.adam_step(self.flat[:self.n_active], self.gflat[:self.n_active], self.m, self.v, lr, betas[0], betas[1], eps,
-                      weight_decay, self.step)
+        n = self.n_active if upto is None else min(int(upto), self.n_active)
+        ops.adam_step(self.flat[:n], self.gflat[:n], self.m[:n], self.v[:n], lr, betas[0], betas[1], eps, weight_decay, self.step)
         self.version += 1
 
 
@@ -251,7 +253,9 @@ class RnnStack:
                          for _ in range(num_layers)]
         self.packed_b = [[torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.ndir)]
                          for _ in range(num_layers)]
-        self.store = [torch.bfloat16 if (prec == BF16 and H % 2 == 0) else torch.float32 for layer in range(num_layers)]
+        # heads mode slices a layer's input per head at multiples of H: bf16 rows then need H % 8 == 0
+        ok16 = prec == BF16 and H % 2 == 0 and (mode == "bidir" or H % 8 == 0 or num_layers == 1)
+        self.store = [torch.bfloat16 if ok16 else torch.float32 for layer in range(num_layers)]
         # bf16 layers whose widths are multiples of 8 take the bf16-stored-operand products: their gate-interleaved
         # W_ih image is padded the way ops.mm16_nt reads it (w_img; w_gl is its [rows, in_p] corner)
         self.mm16 = [MM16 and self.store[layer] == torch.bfloat16 and H % 8 == 0 for layer in range(num_layers)]
@@ -1093,8 +1097,6 @@ class VAEEngine:
         layout += [(n, False) for n in ("fc_mu.weight", "fc_mu.bias", "fc_logvar.weight", "fc_logvar.bias",
                                         "decoder_mlp.0.weight", "decoder_mlp.0.bias", "decoder_mlp.2.weight",
                                         "decoder_mlp.2.bias")]
-        layout += EmbBlock.layout("Emb_decoder.", nb + nc, nn)
-        layout += [("Emb_hidden_decoder.weight", False), ("Emb_hidden_decoder.bias", False)]
         head_w, head_b = [], []
         if nb:
             head_w.append("bins_linear.weight"); head_b.append("bins_linear.bias")
@@ -1103,10 +1105,16 @@ class VAEEngine:
         if nn:
             head_w.append("nums_linear.weight"); head_b.append("nums_linear.bias")
         layout += [(n, k > 0) for k, n in enumerate(head_w)] + [(n, k > 0) for k, n in enumerate(head_b)]
+        # the conditioning branch of the decoder comes last: without a cond it receives no gradient and the
+        # optimizer step stops in front of it (torch.optim.Adam skips parameters whose grad is None)
+        first_cond = len(layout)
+        layout += EmbBlock.layout("Emb_decoder.", nb + nc, nn)
+        layout += [("Emb_hidden_decoder.weight", False), ("Emb_hidden_decoder.bias", False)]
         self.head_w0, self.head_b0 = head_w[0], head_b[0]
         self.NH = nb + sum(self.cards) + nn
         inactive = ["time_encode.0.weight", "time_encode.0.bias", "time_encode.2.weight", "time_encode.2.bias"]
         self.fp = FlatParams(module, layout, inactive, device)
+        self.n_without_cond = self.fp.offsets[layout[first_cond][0]]
         self.enc = RnnStack(self.fp, CELL_GRU, self.H, self.F, self.L, enc_dirs, "heads", self.prec)
         self.emb = EmbBlock(self.fp, "Emb.", nb, nc, nn, self.cards, self.E, self.prec)
         self.emb_dec = EmbBlock(self.fp, "Emb_decoder.", nb, nc, nn, self.cards, self.E, self.prec)

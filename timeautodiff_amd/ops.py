@@ -23,9 +23,54 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def norm_device(dev=None):
+    """An indexed device: 'cuda' / None -> the current device, so that 'cuda' and 'cuda:0' compare equal."""
+    dev = torch.device("cuda" if dev is None else dev)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def device_scope(pick):
+    """Decorator for the package's entry points: the call runs with the device ``pick(*args, **kwargs)`` names as
+    the current one (None or the device that is current already: no switch), because every launch goes to the
+    current device's stream."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrap(*args, **kwargs):
+            dev = pick(*args, **kwargs)
+            if dev is not None:
+                dev = torch.device(dev)
+            if dev is None or dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+                return fn(*args, **kwargs)
+            with torch.cuda.device(dev):
+                return fn(*args, **kwargs)
+        return wrap
+    return deco
+
+
+def _first_cuda(*cands):
+    """Device of the first CUDA tensor among the candidates, else of the first object that knows its engine."""
+    for c in cands:
+        if isinstance(c, torch.Tensor) and c.is_cuda:
+            return c.device
+    for c in cands:
+        eng = getattr(c, "_eng", None) or getattr(c, "eng", None)
+        if eng is not None:
+            return eng.device
+    return None
+
+
 def _chk_dev(t):
+    """Launches go to the current stream of the CURRENT device: an operand on another device would hand that
+    stream pointers of a GPU it cannot reach (a memory fault), so it is rejected here."""
     if not t.is_cuda:
         raise _lib.TadError("libtad_hip ops need device tensors (no CPU path exists)")
+    if t.device.index != torch.cuda.current_device():
+        raise _lib.TadError(f"operand on {t.device} while cuda:{torch.cuda.current_device()} is the current device: "
+                            f"call under torch.cuda.device({t.device.index}) (the engines and trainers of this package do)")
 
 
 def as2d(t, dtype=torch.float32):
@@ -442,12 +487,12 @@ def posenc_fwd(t, t_stride, rows, H, inv_max, w, b, scale, shift, out):
 
 def silu_fwd(z, a):
     assert z.is_contiguous() and a.is_contiguous()
-    _call("tad_silu_fwd" + _sfx(a), z.numel(), z.data_ptr(), a.data_ptr(), _stream())
+    _call("tad_silu_fwd" + _sfx(a), z.numel(), _ptr(z), _ptr(a), _stream())
 
 
 def silu_bwd(z, da, dz):
     assert z.is_contiguous() and da.is_contiguous() and dz.is_contiguous()
-    _call("tad_silu_bwd" + _sfx(dz), z.numel(), z.data_ptr(), da.data_ptr(), dz.data_ptr(), _stream())
+    _call("tad_silu_bwd" + _sfx(dz), z.numel(), _ptr(z), _ptr(da), _ptr(dz), _stream())
 
 
 def layernorm_fwd(x, gamma, beta, y, mean_rstd, eps=1e-5):
