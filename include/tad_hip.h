@@ -255,6 +255,12 @@ int tad_sampler_tail(int prec, int64_t rows, int D, int K, int H, const float* h
 int tad_mse_loss(int64_t n, const float* pred, const float* target, float grad_scale, float* dpred,
                  float* loss_sum, tad_stream_t stream);
 
+/* Squared L2 norm of a flat buffer: out_sum[0] += sum g[i]^2, one launch (wave reductions, one atomic per
+ * workgroup).  For the gradient norm of a step over the flat gradient buffer -- the check a data-parallel run uses to
+ * see that every rank holds the same reduced gradient, and what torch.nn.utils.clip_grad_norm_ would compute; the
+ * reference's loops (DIFF.py:318-325, VAE.py:341-345) do not clip. */
+int tad_grad_norm_sq(int64_t n, const float* g, float* out_sum, tad_stream_t stream);
+
 /* compute_sine_cosine (DIFF.py:14-32, VAE.py:24-42) with num_terms = 8:
  * out[r, j*8+k] = sin(2^k pi x[r,j]), out[r, 8n + j*8+k] = cos(...). */
 int tad_sincos_features(int64_t rows, int n_nums, const float* x, int64_t ldx, float* out, int64_t ldo,

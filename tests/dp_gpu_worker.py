@@ -1,0 +1,89 @@
+"""One rank of the data-parallel rehearsal on a single GPU (started by test_gpu_dp.py as a fresh process):
+3 steps of DiffusionTrainer and of VAETrainer (+ eval_loss) and one DIFF.sample on a batch that the ranks do not
+divide evenly, with a gloo group holding device tensors.  Rank 0 writes what the test compares.
+usage: python dp_gpu_worker.py RANK WORLD PORT OUT.npz"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pg = True if world > 1 else None
+    from timeautodiff_amd import DIFF, VAE, ops
+    dev = torch.device("cuda:0")
+    res = {}
+    # ---- denoiser: mixed schema, batch 7 (ranks take 3 and 4 windows)
+    torch.manual_seed(7)
+    random.seed(7)
+    N, T, K, H, E = 20, 8, 6, 24, 16
+    nb, nc, nn, cards = 1, 2, 3, [3, 5]
+    F = nb + nc + nn
+    g = torch.Generator().manual_seed(11)
+    cond = torch.cat([torch.randint(0, 2, (N, T, 1), generator=g).float()] +
+                     [torch.randint(0, c, (N, T, 1), generator=g).float() for c in cards] + [torch.rand(N, T, nn, generator=g)], -1)
+    ti = torch.randn(N, T, 8, generator=g)
+    lat = torch.randn(N, T, K, generator=g)
+    model = DIFF.BiRNN_score(K, F, H, 2, 100, 8, E, nb, nc, nn, cards)
+    tr = DIFF.DiffusionTrainer(model, lat, ti, cond, batch_size=7, lr=1e-3, dtype="fp32", process_group=pg, draws="reference", dev=dev)
+    losses = []
+    for s in range(3):
+        lo = torch.zeros(1, device=dev)
+        tr.step(loss_out=lo)
+        losses.append(float(lo.item()))
+        if s == 0:
+            fp = tr.eng.fp
+            res["den_grad"] = fp.gflat[:fp.n_active].cpu().numpy().copy()
+            gn = torch.zeros(1, device=dev)
+            ops.grad_norm_sq(fp.gflat[:fp.n_active], gn)
+            res["den_gnorm"] = np.array([float(gn.sqrt().item())])
+    res["den_loss"] = np.array(losses)
+    res["den_w"] = tr.eng.fp.flat[:tr.eng.fp.n_active].cpu().numpy().copy()
+    # ---- sampler: 5 sequences over the ranks, whole batch back on every rank
+    torch.manual_seed(13)
+    xT = torch.randn(5, T, K)
+    zs = torch.randn(100, 5, T, K)
+    tg = torch.linspace(0, 1, T).view(1, T, 1).repeat(5, 1, 1)
+    x = DIFF.sample(tg, 5, T, K, 100, model, ti[:5], cond[:5], None, noise=dict(x_T=xT, z=zs), process_group=pg)
+    assert tuple(x.shape) == (5, T, K)
+    res["sample"] = x.cpu().numpy()
+    xl = DIFF.sample(tg, 5, T, K, 100, model, ti[:5], cond[:5], None, noise=dict(x_T=xT, z=zs), process_group=pg, local_only=True)
+    res["sample_local_rows"] = np.array([xl.shape[0]])
+    # ---- VAE: batch 7, validation set of 5
+    torch.manual_seed(17)
+    random.seed(17)
+    ae = VAE.DeapStack(1, nb, nc, nn, cards, F, H, 2, E, 8, 6)
+    mask = (torch.rand(N, T, F, generator=g) < 0.8).float()
+    dd = dict(response_train=cond[:15] * mask[:15], target_mask_train=mask[:15], cond_train=cond[:15] * (1 - mask[:15]),
+              response_val=cond[15:] * mask[15:], target_mask_val=mask[15:], cond_val=cond[15:] * (1 - mask[15:]))
+    vt = VAE.VAETrainer(ae, dd, batch_size=7, lr=2e-4, weight_decay=1e-6, dtype="fp32", process_group=pg, dev=dev)
+    eps_g = torch.Generator().manual_seed(19)
+    vl, parts, ev = [], [], []
+    for s in range(3):
+        vl.append(vt.train_step(0.1, eps=torch.randn(7, T, 6, generator=eps_g)))
+        parts.append(vt.parts.cpu().numpy().copy())
+        if s == 0:
+            res["vae_grad"] = vt.eng.fp.gflat[:vt.eng.fp.n_active].cpu().numpy().copy()
+        ev.append(vt.eval_loss(0.1, eps=torch.randn(5, T, 6, generator=eps_g)))
+    res["vae_loss"] = np.array(vl)
+    res["vae_parts"] = np.stack(parts)
+    res["vae_eval"] = np.array(ev)
+    res["vae_w"] = vt.eng.fp.flat[:vt.eng.fp.n_active].cpu().numpy().copy()
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(out, **res)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

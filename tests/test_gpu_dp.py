@@ -1,0 +1,53 @@
+"""Data parallelism rehearsed on ONE GPU: two fresh processes share the card, hold a gloo group over device tensors
+and run the trainers' real entry points (DiffusionTrainer.step, VAETrainer.train_step / eval_loss, DIFF.sample) with
+``process_group``; the result must equal the one-process run on the same draws.  The global batch (7, validation 5,
+sampling 5) is not divisible by the number of ranks.  fp32; tolerances: 2e-5 relative on losses and gradients (the
+ranks sum their halves in a different order than one process sums the whole), 1e-4 on weights after three steps."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def test_two_ranks_on_one_gpu_equal_one_process(tmp_path):
+    worker = os.path.join(HERE, "dp_gpu_worker.py")
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    subprocess.run([sys.executable, worker, "0", "1", "0", one], check=True, timeout=300)
+    port = _port()
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), two]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a, b = np.load(one), np.load(two)
+    # denoiser: loss of every step, the reduced gradient of the first step (and its norm, the cross-rank equality
+    # check a training loop would use), the weights after three steps
+    assert np.max(np.abs(a["den_loss"] - b["den_loss"]) / np.abs(a["den_loss"])) < 2e-5
+    assert _rel(b["den_grad"], a["den_grad"]) < 2e-5
+    assert abs(float(b["den_gnorm"][0]) - float(a["den_gnorm"][0])) < 2e-5 * float(a["den_gnorm"][0])
+    assert abs(float(a["den_gnorm"][0]) - float(np.linalg.norm(a["den_grad"].astype(np.float64)))) < 1e-5 * float(a["den_gnorm"][0])
+    assert _rel(b["den_w"], a["den_w"]) < 1e-4
+    # sampler: every rank returns the whole batch, identical to the one-process trajectory; local_only returns the slice
+    assert b["sample"].shape == a["sample"].shape and _rel(b["sample"], a["sample"]) < 1e-6
+    assert int(b["sample_local_rows"][0]) == 2 and int(a["sample_local_rows"][0]) == 5
+    # VAE: total loss, all loss parts (bce, mse, ce per column, kld sums), validation loss, gradient, weights
+    assert np.max(np.abs(a["vae_loss"] - b["vae_loss"]) / np.abs(a["vae_loss"])) < 2e-5
+    assert np.max(np.abs(a["vae_parts"] - b["vae_parts"]) / np.maximum(np.abs(a["vae_parts"]), 1e-6)) < 2e-5
+    assert np.max(np.abs(a["vae_eval"] - b["vae_eval"]) / np.abs(a["vae_eval"])) < 2e-5
+    assert _rel(b["vae_grad"], a["vae_grad"]) < 2e-5
+    assert _rel(b["vae_w"], a["vae_w"]) < 1e-4

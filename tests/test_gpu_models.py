@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 BF16_OUT_TOL = 3e-2      # bf16 path vs the fp32 reference: outputs / loss, max-norm relative
-BF16_GRAD_TOL = 1e-1     # bf16 path vs the fp32 reference: gradients, relative L2 per tensor (H >= 200 shapes)
+BF16_GRAD_TOL = 1e-1     # bf16 path vs the fp32 reference fixture: gradient norms (informative bound; the binding check
+                         # of the bf16 path is the emulating oracle below, at BF16_EMU_GRAD_TOL)
 BF16_EMU_TOL = 5e-3      # bf16 path vs the oracle with operands rounded to bf16 at the same points: outputs
 BF16_EMU_GRAD_TOL = 2e-2  # ... gradients, relative L2 per tensor
 
@@ -119,6 +120,17 @@ def test_denoiser_h200_vs_reference_golden(dev, dtype):
     pred, loss, grads = _denoiser_step(m, dev, data, z["t"], z["i_idx"], z["noise"])
     ot, gt = (TOL, TOL) if dtype == "fp32" else (BF16_OUT_TOL, BF16_GRAD_TOL)
     assert fu.rel_err(pred, z["pred"]) < ot
+    if dtype == "bf16":
+        # the binding check at this hidden size: the oracle with operands rounded to bf16 at the kernels' rounding
+        # points, 5e-3 on the output and 2e-2 (relative L2) on every gradient tensor
+        sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+        _, alphas = oops.schedule(100)
+        with oops.bf16_operands(storage=True):
+            oloss, opred, ograds = oden.loss_and_grads(sd, data["latent"], z["t"], z["i_idx"], z["noise"], data["time_info"],
+                                                       data["cond"], sch, alphas)
+        assert fu.rel_err(pred, opred) < BF16_EMU_TOL and abs(loss - oloss) < BF16_EMU_TOL * oloss
+        errs = {k: grad_err(grads[k], v.reshape(grads[k].shape), dtype) for k, v in ograds.items()}
+        assert max(errs.values()) < BF16_EMU_GRAD_TOL, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
     gs, gh = fu.sub(z, "gs"), fu.sub(z, "gh")
     assert set(gs) == set(grads)
     for k in gs:
@@ -455,19 +467,22 @@ BASELINE_SHAPES = {
     "metro_T48_H512": (dict(n_bins=0, n_cats=3, n_nums=5, cards=[12, 1, 11]), 512, 48, 3, 512, "bern"),       # Metro_Traffic
     "etth1_T96_H200": (dict(n_bins=0, n_cats=0, n_nums=7, cards=[]), 200, 96, 3, 512, "ones"),                # ETTh1 long windows
     "airq_T48_H512": (dict(n_bins=0, n_cats=0, n_nums=13, cards=[]), 512, 48, 2, 512, "bern"),                # AirQuality, 10 % point mask
+    "energy_T24_H200": (dict(n_bins=0, n_cats=1, n_nums=27, cards=[8]), 200, 24, 4, 512, "ones"),             # energy_data (the bench shape)
 }
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", list(BASELINE_SHAPES))
-def test_denoiser_at_baseline_model_dimensions_vs_oracle(dev, name):
-    """BiRNN_score at the hidden size, window length and column schema of the Metro / ETTh1 / AirQuality workloads
-    (H = 512 takes the two-chunks-per-wave and gate-by-gate forms of the sequence kernels), small batch, fp32:
-    output, loss and every parameter gradient against the oracle on the same seeded inputs, 1e-4."""
+def test_denoiser_at_baseline_model_dimensions_vs_oracle(dev, name, dtype):
+    """BiRNN_score at the hidden size, window length and column schema of the Metro / ETTh1 / AirQuality / energy
+    workloads (H = 512 takes the two-chunks-per-wave and gate-by-gate forms of the sequence kernels), small batch:
+    output, loss and every parameter gradient against the oracle on the same seeded inputs -- fp32 1e-4; bf16 against
+    the oracle that rounds operands and stored tensors to bf16 at the kernels' rounding points, 5e-3 / 2e-2."""
     sd_, H, T, B, _, _ = BASELINE_SHAPES[name]
     sch = Schema(sd_["n_bins"], sd_["n_cats"], sd_["n_nums"], list(sd_["cards"]))
     K, E = 6, 128
     meta = dict(K=K, H=H, E=E, seed=91)
-    m = _make_denoiser(meta, sch, dev, "fp32")
+    m = _make_denoiser(meta, sch, dev, dtype)
     sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
     data = fu.make_data(sd_, N=B, T=T, K=K, seed=92, mask_kind="ones")
     rng = np.random.default_rng(93)
@@ -476,22 +491,30 @@ def test_denoiser_at_baseline_model_dimensions_vs_oracle(dev, name):
     noise = rng.standard_normal((B, T, K)).astype(np.float32)
     pred, loss, grads = _denoiser_step(m, dev, data, t, i_idx, noise)
     _, alphas = oops.schedule(100)
-    oloss, opred, ograds = oden.loss_and_grads(sd, data["latent"], t, i_idx, noise, data["time_info"], data["cond"], sch, alphas)
-    assert fu.rel_err(pred, opred) < TOL
-    assert abs(loss - oloss) < TOL * abs(oloss)
-    errs = {k: fu.rel_err(grads[k], v.reshape(grads[k].shape)) for k, v in ograds.items()}
-    assert max(errs.values()) < TOL, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    if dtype == "fp32":
+        oloss, opred, ograds = oden.loss_and_grads(sd, data["latent"], t, i_idx, noise, data["time_info"], data["cond"], sch, alphas)
+        ot, gt = TOL, TOL
+    else:
+        with oops.bf16_operands(storage=True):
+            oloss, opred, ograds = oden.loss_and_grads(sd, data["latent"], t, i_idx, noise, data["time_info"], data["cond"], sch, alphas)
+        ot, gt = BF16_EMU_TOL, BF16_EMU_GRAD_TOL
+    assert fu.rel_err(pred, opred) < ot
+    assert abs(loss - oloss) < ot * abs(oloss)
+    errs = {k: grad_err(grads[k], v.reshape(grads[k].shape), dtype) for k, v in ograds.items()}
+    assert max(errs.values()) < gt, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
 
 
-@pytest.mark.parametrize("name", ["metro_T48_H512", "airq_T48_H512"])
-def test_vae_at_baseline_model_dimensions_vs_oracle(dev, name):
-    """DeapStack at hidden 512 / T = 48 with the Metro (cards [12, 1, 11]) and AirQuality (13 numericals) schemas and a
-    Bernoulli(0.1) int32 point mask: latents, heads, the masked mixed loss and every gradient against the oracle, fp32."""
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["metro_T48_H512", "airq_T48_H512", "energy_T24_H200"])
+def test_vae_at_baseline_model_dimensions_vs_oracle(dev, name, dtype):
+    """DeapStack at hidden 512 with the Metro (cards [12, 1, 11], T = 48), AirQuality (13 numericals, T = 48; both with a
+    Bernoulli(0.1) int32 point mask) and energy (1 categorical of 8 + 27 numericals, T = 24) schemas: latents, heads,
+    the masked mixed loss and every gradient against the oracle -- fp32 1e-4; bf16 against the bf16-emulating oracle."""
     sd_, _, T, B, Hv, mk = BASELINE_SHAPES[name]
     sch = Schema(sd_["n_bins"], sd_["n_cats"], sd_["n_nums"], list(sd_["cards"]))
     L, E, beta = 6, 128, 0.05
     meta = dict(H=Hv, E=E, L=L, seed=95)
-    ae = _make_vae(meta, sch, dev, "fp32")
+    ae = _make_vae(meta, sch, dev, dtype)
     sd = {k: v.detach().cpu().numpy().copy() for k, v in ae.state_dict().items()}
     data = fu.make_data(sd_, N=B, T=T, K=L, seed=96, mask_kind=mk)
     eps = np.random.default_rng(97).standard_normal((B, T, L)).astype(np.float32)
@@ -508,12 +531,19 @@ def test_vae_at_baseline_model_dimensions_vs_oracle(dev, name):
     torch.cuda.synchronize()
     p = parts.tolist()
     total, _ = eng.total_loss(p[:2 + sch.n_cats], p[2 + max(sch.n_cats, 1)], beta, rows)
-    ototal, ores, ograds = ovae.loss_and_grads(sd, data["response"] + data["cond"], data["mask"], data["cond"], eps, np.float32(beta), sch)
-    assert fu.rel_err(zz.cpu().numpy(), ores["z"]) < TOL and fu.rel_err(mu.cpu().numpy(), ores["mu"]) < TOL
-    assert abs(total - ototal) < TOL * abs(ototal)
+    if dtype == "fp32":
+        ototal, ores, ograds = ovae.loss_and_grads(sd, data["response"] + data["cond"], data["mask"], data["cond"], eps, np.float32(beta), sch)
+        ot, gt = TOL, TOL
+    else:
+        with oops.bf16_operands(storage=True):
+            ototal, ores, ograds = ovae.loss_and_grads(sd, data["response"] + data["cond"], data["mask"], data["cond"], eps,
+                                                       np.float32(beta), sch)
+        ot, gt = BF16_EMU_TOL, BF16_EMU_GRAD_TOL
+    assert fu.rel_err(zz.cpu().numpy(), ores["z"]) < ot and fu.rel_err(mu.cpu().numpy(), ores["mu"]) < ot
+    assert abs(total - ototal) < ot * abs(ototal)
     grads = {k: eng.fp.g(k).cpu().numpy() for k in eng.fp.offsets if eng.fp.offsets[k] < eng.fp.n_active}
-    errs = {k: fu.rel_err(grads[k], v.reshape(grads[k].shape)) for k, v in ograds.items()}
-    assert max(errs.values()) < TOL, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    errs = {k: grad_err(grads[k], v.reshape(grads[k].shape), dtype) for k, v in ograds.items()}
+    assert max(errs.values()) < gt, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
 
 
 def test_sampler_long_windows_vs_oracle(dev):

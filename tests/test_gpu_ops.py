@@ -835,3 +835,14 @@ def test_linear_bwd_weight_skinny_strided_operands(ops, dev, prec):
         assert fu.rel_err(got[:, 4:4 + K], ref + 0.25) < F32_TOL
         assert np.all(got[:, :4] == 0.25) and np.all(got[:, 4 + K:] == 0.25)
         assert fu.rel_err(db.cpu().numpy(), dY.astype(np.float64).sum(0)) < F32_TOL
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1027, 3476296])
+def test_grad_norm_sq(ops, dev, n):
+    """Sum of squares of a flat buffer against a float64 sum; accumulates into its output (fp32 partial sums: 1e-5)."""
+    g = torch.randn(n + 4, device=dev)[4:]                 # 16-byte aligned, odd lengths exercise the tail
+    out = torch.full((1,), 2.5, device=dev)
+    ops.grad_norm_sq(g, out)
+    torch.cuda.synchronize()
+    ref = 2.5 + float((g.double() ** 2).sum())
+    assert abs(float(out.item()) - ref) < 1e-5 * ref

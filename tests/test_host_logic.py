@@ -131,7 +131,12 @@ def _dp_worker(rank, world, port, ret):
         keys = sorted(grads)
         flat = torch.from_numpy(np.concatenate([grads[k].ravel() for k in keys]).astype(np.float32))
         loss_sum = torch.tensor([loss * (hi - lo) * T * K], dtype=torch.float64)
-        plan.all_reduce(flat, loss_sum)
+        # two buckets started asynchronously (the trainer's pattern), then the loss with a blocking call
+        nh = flat.numel() // 3
+        pending = [plan.all_reduce_async(flat[:nh]), plan.all_reduce_async(flat[nh:])]
+        for w in pending:
+            w.wait()
+        plan.all_reduce(loss_sum)
         gathered = plan.all_gather_cat(torch.from_numpy(pred.astype(np.float32)))
         if rank == 0:
             ret["flat"] = flat.numpy()

@@ -237,7 +237,9 @@ class DiffusionTrainer:
         self.plan = DataParallelPlan(self.B, process_group)
         self.draws = draws
         self.alphas = alphas.to(d)
-        self.loss_sum = torch.zeros(1, device=d)
+        # the loss partial sum lives right behind the gradients in the flat buffer: the last all-reduce of a step
+        # carries it along
+        self.loss_sum = self.eng.fp.slots(1)
         self.gen = None
         if draws == "device":
             self.gen = torch.Generator(device=d)
@@ -287,11 +289,33 @@ class DiffusionTrainer:
         ops.gather_rows(self.x, idx, self.bx)
         _gather(self.time_info, idx, self.bt)
         _gather(self.cond, idx, self.bc)
-        eng.fp.zero_grad()
-        self.loss_sum.zero_()
-        eng.loss_and_grads(self.bx, t, i_idx, noise, self.bt, self.bc, self.alphas, self.loss_sum,
-                           global_numel=self.B * self.T * self.K)
-        plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.loss_sum)
+        eng.fp.zero_grad()                  # the loss slot with it
+        fp = eng.fp
+        pending = []
+        if plan.world > 1:
+            # two buckets: the head of the flat buffer (input_proj .. fc) is complete once the backward has passed
+            # `proj`; its all-reduce starts there, ordered after the gradient stream's launches so far, and runs
+            # beside the backward of the conditioning path.  The rest (and the loss slot) follows at the end.
+            def first_bucket():
+                fp.release()
+                if fp.side is not None:
+                    fp._fork_ev.record()
+                    fp.side.wait_event(fp._fork_ev)          # LayerNorm's gradients are written on the main stream
+                    with torch.cuda.stream(fp.side):
+                        pending.append(plan.all_reduce_async(fp.gflat[:eng.first_bucket_end]))
+                    fp._side_busy = True
+                else:
+                    pending.append(plan.all_reduce_async(fp.gflat[:eng.first_bucket_end]))
+            eng.on_first_bucket = first_bucket
+        try:
+            eng.loss_and_grads(self.bx, t, i_idx, noise, self.bt, self.bc, self.alphas, self.loss_sum,
+                               global_numel=self.B * self.T * self.K)
+        finally:
+            eng.on_first_bucket = None
+        if plan.world > 1:
+            pending.append(plan.all_reduce_async(fp.gflat[eng.first_bucket_end:fp.n_active + 1]))
+            for w in pending:
+                w.wait()
         eng.fp.adam(self.lr)
         if loss_out is not None:
             torch.div(self.loss_sum, float(self.B * self.T * self.K), out=loss_out)
@@ -341,7 +365,7 @@ def train_diffusion(latent_features, cond_df, data_dict, hidden_dim, num_layers,
 @torch.no_grad()
 @ops.device_scope(lambda t, B, T, F, diffusion_steps, model, *a, **k: ops._first_cuda(model, t))
 def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, noise=None, dtype=None,
-           process_group=None, noise_source="reference", keep=None, streams=None, graph=None):
+           process_group=None, noise_source="reference", keep=None, streams=None, graph=None, local_only=False):
     """reference DIFF.py:333-352: x_T ~ N(0,I), then 100 reverse steps with the step-0 double
     update.  Loop-invariant work (cond path, t_enc, time_encode and their share of `proj`) is
     computed once; the per-step i_enc contribution is a precomputed [steps, H] table.
@@ -349,7 +373,8 @@ def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, 
     Keyword-only extras: noise = dict(x_T=[B,T,F], z=[steps,B,T,F]) to inject the draws;
     noise_source 'reference' (torch CPU generator in the reference's order, staged to the
     device once) or 'device'; dtype overrides the model's compute dtype; process_group shards
-    the batch over ranks with no communication (each rank returns its slice); keep = dict that
+    the batch over ranks with no communication inside the loop; every rank returns the whole batch [B,T,F] (one
+    all-gather of the finished slices) unless local_only=True (then its own slice); keep = dict that
     receives x after the listed steps (keys = step numbers); streams = number of contiguous chunks of
     the batch that walk the loop concurrently on HIP streams of their own (default 2 for batches of
     at least 512 sequences; no value depends on it); graph = True replays the loop as one
@@ -385,4 +410,6 @@ def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, 
         return a[lo:hi].to(device=d, dtype=torch.float32).reshape(nb, T, last).contiguous()
     eng.sample_loop(x, prep(t, 1), prep(time_info, time_info.shape[-1]), prep(cond, cond.shape[-1]), z_all,
                     betas, alphas, keep=keep, streams=streams, graph=graph)
+    if plan.world > 1 and not local_only:
+        return plan.all_gather_cat(x)
     return x

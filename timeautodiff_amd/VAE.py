@@ -194,7 +194,11 @@ class VAETrainer:
         ops.vae_prepare(self.resp_va, self.cond_va, self.mask_va, self.inp_va, self.tgt_va)
         self.Nv = self.resp_va.shape[0]
         self.vplan = DataParallelPlan(self.Nv, process_group)
-        self.parts = torch.zeros(3 + max(eng.nc, 1), device=d)      # [bce, mse, ce_0.., kld] partial sums
+        # [bce, mse, ce_0.., kld] partial sums: right behind the gradients in the flat buffer when they fit there, so
+        # that one all-reduce carries gradients and loss terms together
+        npart = 3 + max(eng.nc, 1)
+        self.parts_in_flat = npart <= eng.fp.SLOTS
+        self.parts = eng.fp.slots(npart) if self.parts_in_flat else torch.zeros(npart, device=d)
         nb = self.plan.local_count
         ws = eng.ws
         self.b_inp = ws.get("batch.inp", (nb, self.T, self.F))
@@ -243,7 +247,10 @@ class VAETrainer:
         eng.decoder(z, self.b_mask, self.b_cond, target=self.b_tgt, scales=eng.loss_scales(rows), loss_parts=self.parts,
                     train=True)
         eng.backward(beta, rows)
-        plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.parts)
+        if self.parts_in_flat:
+            plan.all_reduce(eng.fp.gflat[:eng.fp.n_active + self.parts.numel()])
+        else:
+            plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.parts)
         eng.fp.adam(self.lr, weight_decay=self.wd, upto=None if self.cond_tr is not None else eng.n_without_cond)
         if own_draw and prefetch:
             # the next minibatch's indices (python `random`, the reference's generator for them, VAE.py:340) are

@@ -33,6 +33,19 @@ __device__ __forceinline__ void block_atomic_sum(float v, float* out) {
   __syncthreads();
 }
 
+// Sum of squares of a flat buffer: 16-byte loads, per-lane partial sums over a grid stride, one wave reduction and one
+// atomic per workgroup (the buffer is the flat gradient: a few million floats, one pass at HBM rate).
+__global__ void sumsq_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ out) {
+  const int64_t n4 = n >> 2;
+  float acc = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(g)[e];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; acc += v * v; }
+  block_atomic_sum(acc, out);
+}
+
 // ---------------------------------------------------------------------------
 __global__ void add_noise_kernel(int64_t B, int64_t T, int64_t K, const float* __restrict__ x0,
                                  const float* __restrict__ noise, const int32_t* __restrict__ i_idx,
@@ -504,6 +517,17 @@ extern "C" int tad_mse_loss(int64_t n, const float* pred, const float* target, f
   unsigned g = ew_grid(n, 4);
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(mse_loss_kernel, dim3(g), dim3(EW_BLOCK), 0, EW_STREAM, n, pred, target, grad_scale, dpred, loss_sum);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_grad_norm_sq(int64_t n, const float* g, float* out_sum, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && out_sum && (n == 0 || g), "tad_grad_norm_sq: bad arguments");
+  TAD_CHECK((reinterpret_cast<uintptr_t>(g) & 15) == 0, "tad_grad_norm_sq: the buffer must be 16-byte aligned");
+  if (n == 0) return TAD_OK;
+  unsigned gr = ew_grid(n, 16);
+  if (gr > 1024) gr = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(gr), dim3(EW_BLOCK), 0, EW_STREAM, n, g, out_sum);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

@@ -105,6 +105,7 @@ struct NtParams {
   int64_t M, N, K;
   int act;                                 // TAD_ACT_NONE / RELU / SILU
   int nchunks, nsplit, cps;                // 128-column chunks of N, splits of the chunk range, chunks per split
+  int nks_img;                             // 128-deep slabs the weight image holds: ceil(K / 128)
   int64_t nitems;                          // row panels * nsplit
   int stagger;                             // start delay of every other workgroup, in units of 4096 cycles
   int dbg;                                 // experiments (TAD_MM16_DBG): 1 = no epilogue, 2 = no MFMAs, 4 = no ring loads
@@ -183,7 +184,9 @@ __global__ __launch_bounds__(64 * NT_NW, KS16 <= 36 ? 2 : 1) void mm16_nt_kernel
   const int64_t chunk_bytes = 2ll * NT_BN * p.ldw;
   auto issue = [&](int q, int stage) {     // slab q of the item (beyond the end: the last slab again, keeps the counts uniform)
     const int qq = q < total ? q : total - 1;
-    const int c = qq / NKS, s = qq - c * NKS;
+    const int c = qq / NKS;
+    int s = qq - c * NKS;
+    if (s >= p.nks_img) s = p.nks_img - 1;   // the image is ceil(K / 128) slabs wide; a slab beyond meets zero rows of A: any finite values do
     unsigned char* st = ring + stage * NT_STAGE_BYTES + wave * PW * 1024;
     const unsigned char* src = wbase + (int64_t)(c_first + c) * chunk_bytes + 2 * NT_KD * s;
 #pragma unroll
@@ -572,18 +575,21 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
   const int tstep = T > 0 ? TN_BK % T : 0;
   auto issue = [&](int q, int stage) {
     unsigned char* st = smem + stage * TN_STAGE + wave * 2048;
-    const int64_t m0 = m_beg + (int64_t)(q < nslab ? q : nslab - 1) * TN_BK;     // beyond the end: the last slab again (keeps the counts uniform)
+    // beyond the end of the range the loads only keep the counts uniform: they read the zero page (the time
+    // positions below are those of real slabs only, so no row may be derived from them there)
+    const bool live = q < nslab;
+    const int64_t m0 = m_beg + (int64_t)(live ? q : nslab - 1) * TN_BK;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int64_t m = m0 + 2 * (2 * wave + j) + fsub;
-      const bool okm = m < m_end;
+      const bool okm = live && m < m_end;
       const unsigned char* sa = okm ? abase + 2 * (m * p.lda + ca[j]) : zero;
       glds16(sa, st + j * 1024);
       bool okb = okm;
       if (T > 0) okb = okb && (unsigned)(tpos[j] + shift) < (unsigned)T;
       const unsigned char* sb = okb ? bbase + 2 * ((m + shift) * J.ldb + cb[j]) : zero;
       glds16(sb, st + TN_IMG + j * 1024);
-      if (T > 0 && q < nslab) { tpos[j] += tstep; if (tpos[j] >= T) tpos[j] -= T; }
+      if (T > 0 && live) { tpos[j] += tstep; if (tpos[j] >= T) tpos[j] -= T; }
     }
   };
   issue(0, 0); issue(1, 1); issue(2, 2);
@@ -711,6 +717,7 @@ extern "C" int tad_mm16_nt(int64_t M, int64_t N, int64_t K, const void* A16, int
   p.res = residual; p.ld_res = ld_res; p.res16 = res_dtype == TAD_BF16;
   p.relu = relu_of; p.ld_relu = ld_relu; p.relu16 = relu_dtype == TAD_BF16;
   p.M = M; p.N = N; p.K = K; p.act = act;
+  p.nks_img = (int)cdiv64(K, NT_KD);
   const int ks = (int)cdiv64(K, 16);
   hipStream_t s = (hipStream_t)stream;
   if (ks <= 8) return launch_nt<8>(p, s);

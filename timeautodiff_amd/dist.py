@@ -35,17 +35,30 @@ class DataParallelPlan:
         for t in tensors:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def all_gather_cat(self, t, dim=0):
-        """Concatenate per-rank slices (possibly of unequal length) along ``dim`` on every rank."""
+    def all_reduce_async(self, t):
+        """Start summing ``t`` over the ranks; returns a handle whose wait() orders the current stream after the
+        collective (None for a single process).  The collective is ordered after the work enqueued so far on the
+        stream that is current at the call."""
+        if self.world == 1:
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def all_gather_cat(self, t):
+        """Concatenate the per-rank slices (lengths differ by at most one) along dim 0 on every rank: ONE
+        all_gather_into_tensor over slices padded to the longest one, then the padding rows are dropped."""
         if self.world == 1:
             return t
-        sizes = [slice_bounds(self.global_batch, self.world, r) for r in range(self.world)]
-        outs = []
-        for r, (lo, hi) in enumerate(sizes):
-            shape = list(t.shape)
-            shape[dim] = hi - lo
-            buf = t.contiguous() if r == self.rank else torch.empty(shape, dtype=t.dtype, device=t.device)
-            dist.broadcast(buf, src=dist.get_global_rank(self.group, r) if self.group is not dist.group.WORLD else r,
-                           group=self.group)
-            outs.append(buf)
-        return torch.cat(outs, dim=dim)
+        bounds = [slice_bounds(self.global_batch, self.world, r) for r in range(self.world)]
+        longest = max(hi - lo for lo, hi in bounds)
+        tail = tuple(t.shape[1:])
+        mine = torch.zeros((longest,) + tail, dtype=t.dtype, device=t.device)
+        mine[:t.shape[0]].copy_(t)
+        allbuf = torch.empty((self.world * longest,) + tail, dtype=t.dtype, device=t.device)
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo has no single-buffer all-gather for device tensors (rehearsals on one GPU): per-rank views of the same buffer
+            dist.all_gather(list(allbuf.view((self.world, longest) + tail).unbind(0)), mine, group=self.group)
+        else:
+            dist.all_gather_into_tensor(allbuf, mine, group=self.group)
+        if all(hi - lo == longest for lo, hi in bounds):
+            return allbuf
+        return torch.cat([allbuf[r * longest:r * longest + (hi - lo)] for r, (lo, hi) in enumerate(bounds)], 0)

@@ -46,6 +46,8 @@ class FlatParams:
     never get a gradient in the reference) are stored after the active range and are
     excluded from the optimizer and the all-reduce."""
 
+    SLOTS = 16
+
     def __init__(self, module, layout, inactive, device):
         params = dict(module.named_parameters())
         names = [n for n, _ in layout] + list(inactive)
@@ -58,7 +60,9 @@ class FlatParams:
             self.offsets[name] = off
             off += params[name].numel()
         self.n_active = off
-        off = (off + ALIGN - 1) // ALIGN * ALIGN
+        # SLOTS floats behind the active gradients hold the loss partial sums of a step: one all-reduce then carries
+        # gradients and loss together (the same floats of ``flat`` are unused padding)
+        off = (off + self.SLOTS + ALIGN - 1) // ALIGN * ALIGN
         for name in inactive:
             off = (off + ALIGN - 1) // ALIGN * ALIGN
             self.offsets[name] = off
@@ -116,7 +120,12 @@ class FlatParams:
         return self._view(self.gflat, first, rows * cols, (rows, cols))
 
     def zero_grad(self):
-        self.gflat[:self.n_active].zero_()
+        self.gflat[:self.n_active + self.SLOTS].zero_()
+
+    def slots(self, n=1):
+        """n floats right behind the active gradient range (zeroed by zero_grad, reduced with the gradients)."""
+        assert n <= self.SLOTS
+        return self.gflat[self.n_active:self.n_active + n]
 
     def defer(self, fn, *args, **kwargs):
         """Queue a launch whose only result is an accumulation into the gradient buffer.  It is issued on the
@@ -708,7 +717,7 @@ class DenoiserEngine:
         self.imgs = W16Images(self.fp)
         self.emb.use_mm16(self.imgs)
         # the training step keeps what only matrix products read as bfloat16 when every width involved is a multiple of 8
-        self.mm16 = bool(MM16 and self.prec == BF16 and self.H % 8 == 0 and self.emb.mm16 and self.emb.last16
+        self.mm16 = bool(MM16 and self.prec == BF16 and self.H % 8 == 0 and 4 * self.H <= 1024 and self.emb.mm16 and self.emb.last16
                          and all(self.gru.mm16) and all(self.lstm.mm16))
         if self.mm16:
             p_ = self.fp.p
@@ -718,6 +727,12 @@ class DenoiserEngine:
             if self.time_dim % 8 == 0:
                 self.im["te0"] = self.imgs.add(p_("time_encode.0.weight"), fwd=True, tr=False)
         self.ws = Workspace(device)
+        # data parallel: the gradients of input_proj, t_enc, i_enc, proj, the LSTM, LayerNorm and fc occupy the head of
+        # the flat buffer and are complete before the backward of the conditioning path starts: a trainer may reduce
+        # that range over the ranks while the rest of the backward runs (callback, called once per backward)
+        self.first_bucket_end = self.fp.offsets["Emb.embeddings_list.0.weight" if (nb + nc) else
+                                                ("Emb.mlp_nums.0.weight" if nn else "Emb.mlp_output.0.weight")]
+        self.on_first_bucket = None
         self.scale_t = module.t_enc.scale.to(device=device, dtype=torch.float32).contiguous()
         self.shift_t = module.t_enc.shift.to(device=device, dtype=torch.float32).contiguous()
         self.scale_i = module.i_enc.scale.to(device=device, dtype=torch.float32).contiguous()
@@ -859,6 +874,8 @@ class DenoiserEngine:
                  out_wsum=fp.g("t_enc.linear_proj.weight"))
         fp.defer(ops.colsum, dcat[:, 2 * H:2 * H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
                  out_wsum=fp.g("i_enc.linear_proj.weight"))
+        if self.on_first_bucket is not None:
+            self.on_first_bucket()          # gradients of input_proj .. fc (the head of the flat buffer) are all enqueued
         dtenc = dcat[:, 3 * H:]
         dta = ws.get("dta", (BT, H))
         _lin_bwd(fp, prec, dtenc, ta, fp.p("time_encode.2.weight"), fp.g("time_encode.2.weight"), fp.g("time_encode.2.bias"),
@@ -906,6 +923,8 @@ class DenoiserEngine:
                  out_wsum=fp.g("t_enc.linear_proj.weight"))
         fp.defer(ops.colsum, denc[:, H:H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
                  out_wsum=fp.g("i_enc.linear_proj.weight"))
+        if self.on_first_bucket is not None:
+            self.on_first_bucket()          # gradients of input_proj .. fc (the head of the flat buffer) are all enqueued
         dta = ws.get("dta16", (BT, H), dtype=b16)
         ops.mm16_nt(dtenc, im["te2"]["tr"], None, dta, relu_of=ta)
         fp.defer(ops.mm16_tn, dtenc, [dict(b=ta, c=fp.g("time_encode.2.weight"), db=fp.g("time_encode.2.bias"))])

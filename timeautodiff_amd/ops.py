@@ -453,6 +453,12 @@ def mse_loss(pred, target, grad_scale, dpred, loss_sum):
           _stream())
 
 
+def grad_norm_sq(g, out_sum):
+    """out_sum[0] += sum of squares of the contiguous float32 buffer g (one launch)."""
+    assert g.is_contiguous() and g.dtype == torch.float32 and out_sum.dtype == torch.float32
+    _call("tad_grad_norm_sq", g.numel(), _ptr(g), _ptr(out_sum), _stream(), cost=(2.0 * g.numel(), 4.0 * g.numel()))
+
+
 def sincos_features(x_nums, out):
     xp, rows, n, ldx = as2d(x_nums)
     op, rows2, cols, ldo = as2d(out, out.dtype)
