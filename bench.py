@@ -219,6 +219,12 @@ def attach_profiles(roof, kernels):
         pass
 
 
+def note(msg):
+    """Progress line on stderr (stdout carries the one JSON line only)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 class Ctx:
     """What every section of the bench needs: device, rank layout, barrier, max-over-ranks timing."""
 
@@ -395,6 +401,7 @@ def main():
     from timeautodiff_amd import DIFF
 
     # ---- headline: denoiser training at the energy shape, 4096 windows per GPU
+    note("denoiser training, energy shape")
     head, roof, kernels, (model, trainer, time_info, cond) = bench_denoiser(cx, SCHEMA, T, H, B_LOCAL, a.dtype, a.steps, a.warmup)
     attach_profiles(roof, kernels)
     ms_step, train_rate = head["ms_per_step"], head["samples_per_s"]
@@ -402,6 +409,7 @@ def main():
     # ---- sampler: 1k sequences per GPU, 100 reverse steps
     sampler = None
     if not a.no_sampler:
+        note("sampler")
         Bs = B_SAMPLE * world
         tgrid = torch.linspace(0, 1, T, device=dev).view(1, -1, 1).repeat(Bs, 1, 1)
         ti_s, cond_s = time_info[:Bs], cond[:Bs]
@@ -417,6 +425,7 @@ def main():
     vae = vae_h200 = None
     if not a.no_vae:
         vsteps = max(3, a.steps // 2)
+        note("VAE training, hidden 512 and 200")
         vae = bench_vae(cx, SCHEMA, T, VAE_HIDDEN, B_LOCAL, a.dtype, vsteps)
         vae_h200 = bench_vae(cx, SCHEMA, T, H, B_LOCAL, a.dtype, vsteps, trace=False)
 
@@ -427,6 +436,7 @@ def main():
         for name, wl in WORKLOADS.items():
             if name == "energy_T24_H200":
                 continue
+            note(f"denoiser training, {name}")
             o, r, _, keep = bench_denoiser(cx, wl["schema"], wl["T"], wl["H"], wl["big_B"], a.dtype, 5, 2, prime=4, seed=2000)
             del keep
             o["roofline"] = r
@@ -434,14 +444,17 @@ def main():
             torch.cuda.empty_cache()
         for name in ("metro_T48_H512", "airq_T48_H512"):
             wl = WORKLOADS[name]
+            note(f"VAE training, {name}")
             extras["vae_workloads"][name] = bench_vae(cx, wl["schema"], wl["T"], VAE_HIDDEN, wl["big_B"], a.dtype, 4, mask_kind=wl["mask"],
                                                       with_cond=True)
             torch.cuda.empty_cache()
+        note("denoiser training, fp32")
         o, r, _, keep = bench_denoiser(cx, SCHEMA, T, H, B_LOCAL, "fp32", 5, 2, prime=4)
         del keep
         o["roofline"] = r
         extras["fp32"] = o
         torch.cuda.empty_cache()
+        note("reference-batch regime")
         extras["reference_batch"] = bench_reference_batch(cx, a.dtype)
 
     if rank == 0:
@@ -455,6 +468,7 @@ def main():
                    model_flops_frac_of_bf16_peak=round(3 * 2 * macs * train_rate / (PEAK_BF16 * world), 4),
                    roofline=roof, kernels=kernels, sampler=sampler, vae=vae, vae_h200=vae_h200, extras=extras)
         if not a.no_cpu_baseline and world == 1:
+            note("CPU baseline (numpy oracle)")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

@@ -35,9 +35,15 @@ def main():
         rd = 2.0 * 1024.0 * sf / max(nf, 1)
         wb = 1024.0 * sw / max(nw, 1)
         res[k] = dict(launches=nf, read_bytes_per_launch=round(rd), write_bytes_per_launch=round(wb), traffic_bytes_per_launch=round(rd + wb))
-    json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bench.py --no-sampler --no-vae --steps 3 --warmup 1",
+    # bytes per optimizer step: everything the process moved, over the number of steps it ran (one Adam launch each;
+    # the synthetic-data generation at start-up is included, a fraction of a percent)
+    steps = max((v["launches"] for k, v in res.items() if k.startswith("adam")), default=0)
+    total = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in res.values())
+    per_step = round(total / steps) if steps else None
+    json.dump(dict(steps=steps, traffic_bytes_per_step=per_step, source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bench.py --no-sampler --no-vae --steps 3 --warmup 1",
                    correction="read = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-byte read requests at 64 bytes); write = WRITE_SIZE x 1024",
                    kernels=res), open(out, "w"), indent=1)
+    print(f"steps {steps}, HBM traffic per step {per_step / 1e9 if per_step else 0:.2f} GB")
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"])[:12]:
         print(f"{v['launches']:5d} x {v['traffic_bytes_per_launch'] / 1e6:9.1f} MB  (rd {v['read_bytes_per_launch'] / 1e6:8.1f} wr {v['write_bytes_per_launch'] / 1e6:8.1f})  {k}")
 

@@ -10,6 +10,6 @@ export TMPDIR=/tmp
 O=$R/gpurun_out/pmc_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- python "$R/bench.py" --no-cpu-baseline --no-sampler --no-vae --steps 3 --warmup 1 > "$O/fetch.log" 2>&1
-timeout -s KILL 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python "$R/bench.py" --no-cpu-baseline --no-sampler --no-vae --steps 3 --warmup 1 > "$O/write.log" 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- python "$R/bench.py" --no-cpu-baseline --no-sampler --no-vae --no-extras --steps 3 --warmup 1 > "$O/fetch.log" 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python "$R/bench.py" --no-cpu-baseline --no-sampler --no-vae --no-extras --steps 3 --warmup 1 > "$O/write.log" 2>&1
 python "$R/scripts/pmc_summarize.py" "$O" "$R/gpurun_out/${TAG}_traffic.json"

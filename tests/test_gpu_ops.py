@@ -319,7 +319,7 @@ def _check_rnn(r, cell, B, T, H, tol):
     assert fu.rel_err(r["dx"], dx_ref) < 4 * tol, "dx"
 
 
-RNN_CASES = [(5, 6, 24, 11), (37, 5, 40, 16), (70, 4, 200, 24), (33, 3, 272, 11), (9, 4, 30, 8), (6, 3, 25, 8)]
+RNN_CASES = [(5, 6, 24, 11), (37, 5, 40, 16), (70, 4, 200, 24), (33, 3, 272, 11), (9, 4, 30, 8), (6, 3, 25, 8), (6, 3, 512, 16)]
 
 
 @pytest.mark.parametrize("prec", [0, 1])

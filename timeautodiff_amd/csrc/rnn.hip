@@ -792,7 +792,9 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, 
   const int pad = bf ? 8 : 4;
   const size_t esz = bf ? 2 : 4;
   size_t lds = (size_t)32 * (G * g.width + pad) * esz;
-  const bool phased = lds > LDS_LIMIT;
+  // the gate-by-gate form also where the one-pass form does not fit the register file: the GRU with two chunks per
+  // wave (H = 512 in bf16) compiles to 16 000 spilled registers per lane and runs 100 times slower than it should
+  const bool phased = lds > LDS_LIMIT || (cell == TAD_CELL_GRU && g.jpw == 2);
   a.lds_ld = (phased ? g.width : G * g.width) + pad;
   lds = (size_t)32 * a.lds_ld * esz;
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_bwd: H=%ld needs %zu bytes of LDS (limit %zu)", (long)H, lds, LDS_LIMIT);
