@@ -333,41 +333,49 @@ def bench_reference_batch(cx, dtype):
     latent, time_info, cond = synth(N + 177, 4242, dev)
     dd = dict(parser=_Parser(), cond_train=cond[:N], time_info_train=time_info[:N])
 
-    def run_diff(n):
+    def run_diff(n, graph):
         torch.manual_seed(1)
         import random
         random.seed(1)
         t0 = time.perf_counter()
-        m = DIFF.train_diffusion(latent[:N], None, dd, H, LAYERS, STEPS_DIFF, n, dtype=dtype, draws="reference")
+        m = DIFF.train_diffusion(latent[:N], None, dd, H, LAYERS, STEPS_DIFF, n, dtype=dtype, draws="reference", graph=graph)
         torch.cuda.synchronize()
         return time.perf_counter() - t0, m
-    run_diff(10)
-    ta, _ = run_diff(20)
-    tb, model = run_diff(120)
-    ms_diff = 1e3 * (tb - ta) / 100
+    ms_d = {}
+    for graph in (False, True):            # kernel by kernel, then as one captured HIP graph per step (the default at this size)
+        run_diff(10, graph)
+        ta, _ = run_diff(20, graph)
+        tb, model = run_diff(220, graph)
+        ms_d[graph] = 1e3 * (tb - ta) / 200
+    ms_diff = ms_d[True]
     ones = torch.ones(N + 177, T, F, device=dev)
     vd = dict(parser=_Parser(), response_train=cond[:N], target_mask_train=ones[:N], cond_train=None,
               response_val=cond[N:], target_mask_val=ones[N:], cond_val=None)
 
-    def run_vae(n):
+    def run_vae(n, graph):
         torch.manual_seed(2)
         import random
         random.seed(2)
         t0 = time.perf_counter()
-        VAE.train_autoencoder(None, 1, VAE_HIDDEN, LAYERS, 2e-4, 1e-6, n, 100, None, 1e-5, 0.1, E, 8, K, dev, vd, dtype=dtype)
+        VAE.train_autoencoder(None, 1, VAE_HIDDEN, LAYERS, 2e-4, 1e-6, n, 100, None, 1e-5, 0.1, E, 8, K, dev, vd, dtype=dtype, graph=graph)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
-    run_vae(5)
-    va = run_vae(10)
-    vb = run_vae(60)
-    ms_vae = 1e3 * (vb - va) / 50
+    ms_v = {}
+    for graph in (False, True):
+        run_vae(5, graph)
+        va = run_vae(10, graph)
+        vb = run_vae(110, graph)
+        ms_v[graph] = 1e3 * (vb - va) / 100
+    ms_vae = ms_v[True]
     tgrid = torch.linspace(0, 1, T, device=dev).view(1, -1, 1).repeat(N, 1, 1)
     DIFF.sample(tgrid, N, T, K, STEPS_DIFF, model, time_info[:N], cond[:N], None, noise_source="device")
     ds = cx.timed(lambda: DIFF.sample(tgrid, N, T, K, STEPS_DIFF, model, time_info[:N], cond[:N], None, noise_source="device"), 2) / 2
     return dict(dtype=dtype, workload="energy_T24_H200",
-                train_diffusion=dict(batch=100, ms_per_step=round(ms_diff, 3), samples_per_s=round(100 / ms_diff * 1e3, 1), draws="reference"),
+                train_diffusion=dict(batch=100, ms_per_step=round(ms_diff, 3), samples_per_s=round(100 / ms_diff * 1e3, 1), draws="reference",
+                                     ms_per_step_kernel_by_kernel=round(ms_d[False], 3), replay="one HIP graph per step"),
                 train_autoencoder=dict(batch=100, hidden=VAE_HIDDEN, ms_per_iteration=round(ms_vae, 3),
-                                       samples_per_s=round(100 / ms_vae * 1e3, 1), includes="validation pass over 177 windows"),
+                                       samples_per_s=round(100 / ms_vae * 1e3, 1), includes="validation pass over 177 windows",
+                                       ms_per_iteration_kernel_by_kernel=round(ms_v[False], 3), replay="one HIP graph per step and per validation pass"),
                 sample=dict(batch=N, ms_per_call=round(1e3 * ds, 2), seqs_per_s=round(N / ds, 1)))
 
 

@@ -321,6 +321,12 @@ int tad_gather_windows(int64_t B, int64_t T, int64_t F, int64_t stride, const fl
  * L2 weight decay, bias correction for step number `step` (1-based). */
 int tad_adam_step(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, tad_stream_t stream);
+/* The same step with its two step-dependent factors read from device memory: coef2 = {lr / (1 - beta1^step),
+ * 1 / sqrt(1 - beta2^step)} as tad_adam_coefficients (host function, the arithmetic of tad_adam_step) computes them.
+ * For launches captured into a HIP graph: the host refreshes coef2 before every replay. */
+void tad_adam_coefficients(float lr, float beta1, float beta2, int step, float* out2);
+int tad_adam_step_dev(int64_t n, float* p, const float* g, float* m, float* v, float beta1, float beta2, float eps,
+                      float weight_decay, const float* coef2, tad_stream_t stream);
 
 /* ------------------------------------------------------------------ VAE family
  * reparametrize (VAE.py:147-150) + KLD partial sum (VAE.py:350-351):

@@ -13,6 +13,7 @@ Extra behaviour is reachable only through keyword-only arguments whose defaults
 reproduce the reference.
 """
 import math
+import os
 import random
 from typing import List, Optional
 
@@ -214,8 +215,14 @@ class DiffusionTrainer:
 
     @ops.device_scope(lambda self, model, *a, **k: k.get("dev") if k.get("dev") is not None else ops._first_cuda(model))
     def __init__(self, model: BiRNN_score, latent, time_info, cond, *, batch_size=None, lr=1e-3, dtype="fp32",
-                 process_group=None, draws="reference", dev=None):
+                 process_group=None, draws="reference", dev=None, graph=None):
         model.set_compute_dtype(dtype)
+        # graph=True: everything of a step after the draws (gathers, add_noise, forward, loss, backward on both streams,
+        # Adam) is captured once as a HIP graph and replayed -- one launch per step for the host instead of a hundred,
+        # which is what a step costs at the reference's batch of 100 windows.  Default: on for batches of at most 512
+        # windows in a single process, where the step is bound by launch latency; TAD_TRAIN_GRAPH=0/1 overrides.
+        self._graph_opt = graph
+        self._graph = None
         self.model = model
         self.eng = model.engine(dev)
         d = self.eng.device
@@ -274,10 +281,74 @@ class DiffusionTrainer:
             noise = torch.randn(B, T, K, device=d, generator=self.gen)
         return dict(idx=idx, t=t, i=i, noise=noise)
 
+    def use_graph(self):
+        env = os.environ.get("TAD_TRAIN_GRAPH")
+        if self.plan.world > 1 or ops.tracing() is not None:
+            return False                       # collectives and per-launch timing events are not captured
+        if self._graph_opt is not None:
+            return bool(self._graph_opt)
+        if env is not None:
+            return env == "1"
+        return self.B <= 512
+
     @ops.device_scope(lambda self, *a, **k: self.eng.device)
     def step(self, draw=None, loss_out=None):
         """One optimizer step (reference DIFF.py:306-325).  ``loss_out`` (1-element device
         tensor view) receives the mean loss of the global batch without a host sync."""
+        if self.use_graph():
+            return self._step_graph(draw, loss_out)
+        return self._step_eager(draw, loss_out)
+
+    def _step_graph(self, draw, loss_out):
+        """The step as a replay of its captured graph; the draws (a handful of launches) stay outside, in the order
+        and from the generators of the eager path, and are copied into the buffers the graph reads."""
+        eng = self.eng
+        d = eng.device
+        dr = draw if draw is not None else self.draw()
+        if self._graph is None:
+            # two eager steps first: they size the workspace, load the code objects and set the kernels' LDS limits
+            # (none of which may happen inside a capture) -- on copies of the state, which is restored afterwards
+            fp = eng.fp
+            keep = (fp.flat.clone(), fp.m.clone(), fp.v.clone(), fp.step)
+            for _ in range(2):
+                self._step_eager(dr, None)
+            fp.flat.copy_(keep[0]); fp.m.copy_(keep[1]); fp.v.copy_(keep[2]); fp.step = keep[3]
+            fp.version += 1
+            B, T, K = self.B, self.T, self.K
+            self._g_in = dict(idx=torch.zeros(B, dtype=torch.int64, device=d), t=torch.zeros(B, T, 1, device=d),
+                              i=torch.zeros(B, dtype=torch.int32, device=d), noise=torch.zeros(B, T, K, device=d))
+            self._g_coef = torch.zeros(2, device=d)
+            self._g_coef_host = torch.zeros(2).pin_memory()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_body(self._g_in["idx"], self._g_in["t"], self._g_in["i"], self._g_in["noise"], captured=True)
+            self._graph = g
+        gi = self._g_in
+        gi["idx"].copy_(dr["idx"], non_blocking=True)
+        gi["t"].copy_(dr["t"], non_blocking=True)
+        gi["i"].copy_(dr["i"], non_blocking=True)
+        gi["noise"].copy_(dr["noise"], non_blocking=True)
+        eng.fp.adam_refresh(self.lr, self._g_coef, self._g_coef_host)
+        self._graph.replay()
+        if loss_out is not None:
+            torch.div(self.loss_sum, float(self.B * self.T * self.K), out=loss_out)
+
+    def _step_body(self, idx, t, i_idx, noise, captured=False):
+        """Gathers, zeroing, add_noise -> forward -> loss -> backward, Adam (single process)."""
+        eng = self.eng
+        ops.gather_rows(self.x, idx, self.bx)
+        _gather(self.time_info, idx, self.bt)
+        _gather(self.cond, idx, self.bc)
+        eng.fp.zero_grad()                  # the loss slot with it
+        eng.loss_and_grads(self.bx, t, i_idx, noise, self.bt, self.bc, self.alphas, self.loss_sum,
+                           global_numel=self.B * self.T * self.K)
+        if captured:
+            eng.fp.adam_captured(self._g_coef)
+        else:
+            eng.fp.adam(self.lr)
+
+    def _step_eager(self, draw=None, loss_out=None):
         eng, plan = self.eng, self.plan
         d = eng.device
         dr = draw if draw is not None else self.draw()
@@ -323,12 +394,13 @@ class DiffusionTrainer:
 
 def train_diffusion(latent_features, cond_df, data_dict, hidden_dim, num_layers, diffusion_steps, n_epochs,
                     num_classes=None, *, batch_size=None, lr=1e-3, dtype="fp32", process_group=None,
-                    draws="reference", losses=None, progress=False):
+                    draws="reference", losses=None, progress=False, graph=None):
     """reference DIFF.py:267-330.  ``cond_df`` and ``num_classes`` are accepted and ignored like
     the reference.  Keyword-only extras: batch_size (default = diffusion_steps, the reference's
     hard-coded choice), lr (Adam default 1e-3), dtype ('fp32' | 'bf16'), process_group (data
     parallel over RCCL), draws ('reference' | 'device'), losses (a list that receives the
-    per-iteration losses, fetched once at the end)."""
+    per-iteration losses, fetched once at the end), graph (replay each step as one captured HIP graph; default: on
+    for batches of at most 512 windows in a single process)."""
     emb_dim = 128
     info = data_dict["parser"].datatype_info()
     n_bins, n_cats, n_nums, cards = info["n_bins"], info["n_cats"], info["n_nums"], info["cards"]
@@ -342,7 +414,7 @@ def train_diffusion(latent_features, cond_df, data_dict, hidden_dim, num_layers,
     model = BiRNN_score(input_size, org_feat_dim, hidden_dim, num_layers, diffusion_steps, time_dim, emb_dim,
                         n_bins, n_cats, n_nums, cards)
     trainer = DiffusionTrainer(model, latent_features, time_info, cond_train, batch_size=batch_size, lr=lr, dtype=dtype,
-                               process_group=process_group, draws=draws)
+                               process_group=process_group, draws=draws, graph=graph)
     hist = torch.zeros(max(n_epochs, 1), device=trainer.eng.device)
     bar = None
     if progress:

@@ -172,7 +172,8 @@ class VAETrainer:
     """Device-resident training state of the VAE (one process per GPU)."""
 
     @ops.device_scope(lambda self, ae, *a, **k: k.get("dev") if k.get("dev") is not None else ops._first_cuda(ae))
-    def __init__(self, ae: DeapStack, data_dict, *, batch_size, lr, weight_decay, dtype="fp32", process_group=None, dev=None):
+    def __init__(self, ae: DeapStack, data_dict, *, batch_size, lr, weight_decay, dtype="fp32", process_group=None, dev=None,
+                 graph=None):
         ae.set_compute_dtype(dtype)
         self.ae = ae
         self.eng = eng = ae.engine(dev)
@@ -207,6 +208,84 @@ class VAETrainer:
         self.b_cond = ws.get("batch.cond", (nb, self.T, self.F)) if self.cond_tr is not None else None
         self.all_indices = list(range(self.N))
         self._next_idx = None
+        # the validation pass works on a batch of another size: it gets a workspace of its own, so that neither pass
+        # re-allocates the other's buffers (and so that captured graphs keep their addresses)
+        from .engine import Workspace
+        self._ws_train, self._ws_eval = eng.ws, Workspace(d)
+        # graph=True: a training step (after its draws) and a validation pass are captured as HIP graphs and replayed
+        # (one graph per value of beta, which the kernels take as a launch argument).  Default: on for batches of at
+        # most 512 windows in a single process; TAD_TRAIN_GRAPH=0/1 overrides.
+        self._graph_opt = graph
+        self._graphs = {}
+        self._g_in = None
+
+    def use_graph(self):
+        import os
+        env = os.environ.get("TAD_TRAIN_GRAPH")
+        if self.plan.world > 1 or ops.tracing() is not None:
+            return False
+        if self._graph_opt is not None:
+            return bool(self._graph_opt)
+        if env is not None:
+            return env == "1"
+        return self.B <= 512
+
+    def _train_body(self, idx_d, eps_l, beta, captured=False):
+        eng = self.eng
+        ops.gather_rows(self.inp_tr, idx_d, self.b_inp)
+        ops.gather_rows(self.tgt_tr, idx_d, self.b_tgt)
+        ops.gather_rows(self.mask_tr, idx_d, self.b_mask)
+        if self.b_cond is not None:
+            ops.gather_rows(self.cond_tr, idx_d, self.b_cond)
+        rows = self.B * self.T
+        eng.fp.zero_grad()
+        self.parts.zero_()
+        nc = eng.nc
+        kld = self.parts[2 + max(nc, 1):]
+        z, mu, lv = eng.encoder(self.b_inp, eps_l, train=True, kld_sum=kld)
+        eng.decoder(z, self.b_mask, self.b_cond, target=self.b_tgt, scales=eng.loss_scales(rows), loss_parts=self.parts,
+                    train=True)
+        eng.backward(beta, rows)
+        upto = None if self.cond_tr is not None else eng.n_without_cond
+        if captured:
+            eng.fp.adam_captured(self._g_coef, weight_decay=self.wd, upto=upto)
+        else:
+            plan = self.plan
+            if self.parts_in_flat:
+                plan.all_reduce(eng.fp.gflat[:eng.fp.n_active + self.parts.numel()])
+            else:
+                plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.parts)
+            eng.fp.adam(self.lr, weight_decay=self.wd, upto=upto)
+
+    def _eval_body(self, eps_l, lo, hi):
+        eng = self.eng
+        self.parts.zero_()
+        nc = eng.nc
+        kld = self.parts[2 + max(nc, 1):]
+        eng.ws = self._ws_eval
+        try:
+            z, mu, lv = eng.encoder(self.inp_va[lo:hi], eps_l, train=False, kld_sum=kld)
+            cond = self.cond_va[lo:hi] if self.cond_va is not None else None
+            eng.decoder(z, self.mask_va[lo:hi], cond, target=self.tgt_va[lo:hi], loss_parts=self.parts, train=False)
+        finally:
+            eng.ws = self._ws_train
+
+    def _graph_for(self, key, build):
+        """The captured graph for ``key`` (built on first use, after two eager runs on saved state)."""
+        g = self._graphs.get(key)
+        if g is None:
+            fp = self.eng.fp
+            keep = (fp.flat.clone(), fp.m.clone(), fp.v.clone(), fp.step)
+            for _ in range(2):
+                build(False)
+            fp.flat.copy_(keep[0]); fp.m.copy_(keep[1]); fp.v.copy_(keep[2]); fp.step = keep[3]
+            fp.version += 1
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                build(True)
+            self._graphs[key] = g
+        return g
 
     def _loss(self, rows, beta):
         """Combine the (all-reduced) partial sums on the host -> python float total."""
@@ -233,25 +312,21 @@ class VAETrainer:
         if eps is None:
             eps = torch.randn(self.B, self.T, eng.lat, device=d)
         eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
-        ops.gather_rows(self.inp_tr, idx_d, self.b_inp)
-        ops.gather_rows(self.tgt_tr, idx_d, self.b_tgt)
-        ops.gather_rows(self.mask_tr, idx_d, self.b_mask)
-        if self.b_cond is not None:
-            ops.gather_rows(self.cond_tr, idx_d, self.b_cond)
         rows = self.B * self.T
-        eng.fp.zero_grad()
-        self.parts.zero_()
-        nc = eng.nc
-        kld = self.parts[2 + max(nc, 1):]
-        z, mu, lv = eng.encoder(self.b_inp, eps_l, train=True, kld_sum=kld)
-        eng.decoder(z, self.b_mask, self.b_cond, target=self.b_tgt, scales=eng.loss_scales(rows), loss_parts=self.parts,
-                    train=True)
-        eng.backward(beta, rows)
-        if self.parts_in_flat:
-            plan.all_reduce(eng.fp.gflat[:eng.fp.n_active + self.parts.numel()])
+        if self.use_graph():
+            if self._g_in is None:
+                self._g_in = dict(idx=torch.zeros(hi - lo, dtype=torch.int64, device=d), eps=torch.zeros(hi - lo, self.T, eng.lat, device=d),
+                                  veps=torch.zeros(self.vplan.hi - self.vplan.lo, self.T, eng.lat, device=d))
+                self._g_coef = torch.zeros(2, device=d)
+                self._g_coef_host = torch.zeros(2).pin_memory()
+            gi = self._g_in
+            gi["idx"].copy_(idx_d, non_blocking=True)
+            gi["eps"].copy_(eps_l, non_blocking=True)
+            g = self._graph_for(("train", float(beta)), lambda cap: self._train_body(gi["idx"], gi["eps"], beta, captured=cap))
+            eng.fp.adam_refresh(self.lr, self._g_coef, self._g_coef_host)
+            g.replay()
         else:
-            plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.parts)
-        eng.fp.adam(self.lr, weight_decay=self.wd, upto=None if self.cond_tr is not None else eng.n_without_cond)
+            self._train_body(idx_d, eps_l, beta)
         if own_draw and prefetch:
             # the next minibatch's indices (python `random`, the reference's generator for them, VAE.py:340) are
             # drawn now, while the device works on this step: reading the loss back below blocks the host
@@ -271,14 +346,14 @@ class VAETrainer:
         if eps is None:
             eps = torch.randn(self.Nv, self.T, eng.lat, device=d)
         lo, hi = plan.lo, plan.hi
-        self.parts.zero_()
-        nc = eng.nc
-        kld = self.parts[2 + max(nc, 1):]
         eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
-        z, mu, lv = eng.encoder(self.inp_va[lo:hi], eps_l, train=False, kld_sum=kld)
-        cond = self.cond_va[lo:hi] if self.cond_va is not None else None
-        eng.decoder(z, self.mask_va[lo:hi], cond, target=self.tgt_va[lo:hi], loss_parts=self.parts, train=False)
-        plan.all_reduce(self.parts)
+        if self.use_graph() and self._g_in is not None:
+            gi = self._g_in
+            gi["veps"].copy_(eps_l, non_blocking=True)
+            self._graph_for("eval", lambda cap: self._eval_body(gi["veps"], lo, hi)).replay()
+        else:
+            self._eval_body(eps_l, lo, hi)
+            plan.all_reduce(self.parts)
         return self._loss(self.Nv * self.T, beta)
 
     @ops.device_scope(lambda self, *a, **k: self.eng.device)
@@ -296,7 +371,7 @@ class VAETrainer:
 
 def _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size, threshold, min_beta,
            max_beta, emb_dim, time_dim, lat_dim, device, data_dict, select, dtype, process_group, noise_source,
-           progress):
+           progress, graph=None):
     info = data_dict["parser"].datatype_info()
     n_bins, n_cats, n_nums, cards = info["n_bins"], info["n_cats"], info["n_nums"], info["cards"]
     N, _, input_size = data_dict["response_train"].shape
@@ -305,7 +380,7 @@ def _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epoch
     if dev is not None and dev.type != "cuda":
         raise RuntimeError("train_autoencoder runs only on an MI355X through libtad_hip.so (device=%r)" % (device,))
     tr = VAETrainer(ae, data_dict, batch_size=batch_size, lr=lr, weight_decay=weight_decay, dtype=dtype,
-                    process_group=process_group, dev=dev)
+                    process_group=process_group, dev=dev, graph=graph)
     eng = tr.eng
     d = eng.device
     T, L = tr.T, eng.lat
@@ -359,19 +434,19 @@ def _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epoch
 
 def train_autoencoder(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size, threshold,
                       min_beta, max_beta, emb_dim, time_dim, lat_dim, device, data_dict, *, dtype="fp32",
-                      process_group=None, noise_source="device", progress=False):
+                      process_group=None, noise_source="device", progress=False, graph=None):
     """reference VAE.py:261-404: weights selected by lowest validation loss.  ``real_df``,
     ``channels`` and ``threshold`` are accepted and ignored like the reference.  Returns
     (ae, latent (sampled z of the training set under the best weights), output dict, history)."""
     return _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size, threshold,
                   min_beta, max_beta, emb_dim, time_dim, lat_dim, device, data_dict, "val", dtype, process_group,
-                  noise_source, progress)
+                  noise_source, progress, graph)
 
 
 def train_autoencoder_best_train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size,
                                  threshold, min_beta, max_beta, emb_dim, time_dim, lat_dim, device, data_dict, *,
-                                 dtype="fp32", process_group=None, noise_source="device", progress=False):
+                                 dtype="fp32", process_group=None, noise_source="device", progress=False, graph=None):
     """reference VAE.py:416-568: weights selected by lowest *training* loss."""
     return _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epochs, batch_size, threshold,
                   min_beta, max_beta, emb_dim, time_dim, lat_dim, device, data_dict, "train", dtype, process_group,
-                  noise_source, progress)
+                  noise_source, progress, graph)

@@ -421,9 +421,12 @@ __global__ void gather_windows_kernel(int64_t B, int T, int F, int64_t stride, c
   }
 }
 
+// coef (optional): device pointer to {step_size, inv_sqrt_bc2}, read instead of the two arguments -- a captured
+// launch then takes the step-dependent bias corrections from memory the host refreshes before every replay
 __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float b1, float b2, float eps, float wd, float step_size,
-                            float inv_sqrt_bc2) {
+                            float inv_sqrt_bc2, const float* __restrict__ coef) {
+  if (coef) { step_size = coef[0]; inv_sqrt_bc2 = coef[1]; }
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const float pe = p[e];
     float ge = g[e];
@@ -743,7 +746,23 @@ extern "C" int tad_adam_step(int64_t n, float* p, const float* g, float* m, floa
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, p, g, m, v, beta1, beta2, eps, weight_decay,
-                     step_size, inv_sqrt_bc2);
+                     step_size, inv_sqrt_bc2, (const float*)nullptr);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" void tad_adam_coefficients(float lr, float beta1, float beta2, int step, float* out2) {
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  out2[0] = (float)((double)lr / bc1);
+  out2[1] = (float)(1.0 / sqrt(bc2));
+}
+
+extern "C" int tad_adam_step_dev(int64_t n, float* p, const float* g, float* m, float* v, float beta1, float beta2, float eps,
+                                 float weight_decay, const float* coef2, tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && p && g && m && v && coef2, "tad_adam_step_dev: bad arguments");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, p, g, m, v, beta1, beta2, eps, weight_decay,
+                     0.f, 0.f, coef2);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

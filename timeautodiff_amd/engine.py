@@ -21,6 +21,9 @@ SAMPLE_FUSED_TAIL = os.environ.get("TAD_SAMPLE_FUSED_TAIL", "1") != "0"
 # by kernel (off by default: at 1k sequences the loop is device-bound and the graph measured no faster)
 SAMPLE_GRAPH = os.environ.get("TAD_SAMPLE_GRAPH", "0") == "1"
 GRAD_IMMEDIATE = os.environ.get("TAD_GRAD_STREAM", "1") == "1"
+# HIP priority of the gradient stream (larger = lower priority): what runs there is off the critical path and must not
+# take compute units from the main stream's kernels
+SIDE_PRIORITY = int(os.environ.get("TAD_SIDE_PRIORITY", "0"))
 # TAD_MM16=0: bf16 precision keeps every activation in fp32 and uses the fp32-operand product kernels throughout
 # (the path of the fp32 mode with operands rounded inside the kernels; experiments and A/B timing)
 MM16 = os.environ.get("TAD_MM16", "1") != "0"
@@ -79,7 +82,7 @@ class FlatParams:
         # weight-gradient products are off the critical path of a backward pass (nothing downstream reads them
         # before the optimizer step): they go to a second HIP stream and fill the compute units that the
         # latency-bound sequence kernels of the main stream leave idle
-        self.side = torch.cuda.Stream(device=device) if (GRAD_STREAM and torch.device(device).type == "cuda") else None
+        self.side = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY) if (GRAD_STREAM and torch.device(device).type == "cuda") else None
         self._fork_ev = torch.cuda.Event() if self.side is not None else None
         self._join_ev = torch.cuda.Event() if self.side is not None else None
         self._side_busy = False
@@ -164,6 +167,23 @@ class FlatParams:
             self._join_ev.record(self.side)
             torch.cuda.current_stream().wait_event(self._join_ev)
             self._side_busy = False
+
+    def adam_captured(self, coef2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, upto=None):
+        """The launch of ``adam`` for a HIP-graph capture: the step-dependent factors are read from the device tensor
+        ``coef2`` (see ``adam_refresh``); the step counter and the parameter version are advanced per replay by
+        ``adam_refresh``, not here."""
+        n = self.n_active if upto is None else min(int(upto), self.n_active)
+        ops.adam_step_dev(self.flat[:n], self.gflat[:n], self.m[:n], self.v[:n], betas[0], betas[1], eps, weight_decay, coef2)
+
+    def adam_refresh(self, lr, coef2, host2=None, betas=(0.9, 0.999)):
+        """Before a replay of a captured step: advance the step counter and put its bias-correction factors where
+        the captured Adam launch reads them."""
+        self.step += 1
+        c0, c1 = ops.adam_coefficients(lr, betas[0], betas[1], self.step)
+        # a fresh pageable tensor per step: the runtime stages it at the call, so the next step's values cannot
+        # overtake a copy that is still queued (a reused pinned buffer would be rewritten under it)
+        coef2.copy_(torch.tensor([c0, c1], dtype=torch.float32), non_blocking=True)
+        self.version += 1
 
     def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, upto=None):
         """One Adam step over the active range, or over its first ``upto`` elements (the rest holds parameters

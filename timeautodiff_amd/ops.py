@@ -579,6 +579,21 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
           float(eps), float(weight_decay), int(step), _stream())
 
 
+def adam_coefficients(lr, beta1, beta2, step):
+    """(lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)) as float32, computed the way tad_adam_step does."""
+    out = (C.c_float * 2)()
+    _lib.load().tad_adam_coefficients(float(lr), float(beta1), float(beta2), int(step), out)
+    return float(out[0]), float(out[1])
+
+
+def adam_step_dev(p, g, m, v, beta1, beta2, eps, weight_decay, coef2):
+    """Adam step whose step-dependent factors come from the 2-element device tensor coef2 (graph replays)."""
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n and coef2.numel() == 2 and coef2.dtype == torch.float32
+    _call("tad_adam_step_dev", n, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), float(beta1), float(beta2), float(eps),
+          float(weight_decay), _ptr(coef2), _stream())
+
+
 # ------------------------------------------------------------------ VAE family
 def vae_reparam_fwd(mu, lv, eps, z, kld_sum):
     _call("tad_vae_reparam_fwd", mu.numel(), mu.data_ptr(), lv.data_ptr(), eps.data_ptr(), z.data_ptr(), _ptr(kld_sum), _stream())
