@@ -255,6 +255,11 @@ int tad_sampler_tail(int prec, int64_t rows, int D, int K, int H, const float* h
 int tad_mse_loss(int64_t n, const float* pred, const float* target, float grad_scale, float* dpred,
                  float* loss_sum, tad_stream_t stream);
 
+/* nn.L1Loss of the post-hoc predictor (Evaluation/predictive_metrics.py:27, 38-40) and its gradient:
+ * loss_sum[0] += sum |pred - target|, dpred = grad_scale * sign(pred - target) (grad_scale = 1 / numel). */
+int tad_l1_loss(int64_t n, const float* pred, const float* target, float grad_scale, float* dpred, float* loss_sum,
+                tad_stream_t stream);
+
 /* Squared L2 norm of a flat buffer: out_sum[0] += sum g[i]^2, one launch (wave reductions, one atomic per
  * workgroup).  For the gradient norm of a step over the flat gradient buffer -- the check a data-parallel run uses to
  * see that every rank holds the same reduced gradient, and what torch.nn.utils.clip_grad_norm_ would compute; the

@@ -351,6 +351,95 @@ def tvmcg_case(ref, name, B, T, F, cont_idx, cat_idx, classes, level, p, seed):
     print(name, float((noisy - ct).abs().max()), int((flipped != ct).sum()))
 
 
+def posthoc_cases(ref):
+    """The post-hoc evaluation networks (reference Evaluation/Metrics.py:54-65 Discriminator,
+    Evaluation/predictive_metrics.py:8-17 PosthocRNN): forward, loss, every gradient, and a 20-step Adam loss curve
+    on recorded minibatch indices (the loop bodies of Metrics.py:91-109 / predictive_metrics.py:30-41)."""
+    import importlib.util
+    import torch
+    import torch.nn as nn
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    M = load(os.path.join(ref, "Evaluation", "Metrics.py"), "ref_metrics")
+    P = load(os.path.join(ref, "Evaluation", "predictive_metrics.py"), "ref_predictive")
+    rng = np.random.default_rng(301)
+    N, T, dim, nb, steps = 48, 8, 5, 16, 20
+    real = rng.random((N, T, dim), dtype=np.float32)
+    fake = (rng.random((N, T, dim), dtype=np.float32) * 0.8 + 0.1).astype(np.float32)
+    # ---- discriminator
+    torch.manual_seed(302)
+    disc = M.Discriminator(dim, 50, 2)
+    out = dict(real=real, fake=fake)
+    for k, v in sd_to_np(disc.state_dict()).items():
+        out["w/" + k] = v
+    xr, xf = torch.from_numpy(real[:nb]), torch.from_numpy(fake[:nb])
+    lr_, _ = disc(xr)
+    lf_, _ = disc(xf)
+    loss = nn.BCEWithLogitsLoss()(lr_, torch.ones_like(lr_)) + nn.BCEWithLogitsLoss()(lf_, torch.zeros_like(lf_))
+    loss.backward()
+    out["logit_real"], out["logit_fake"], out["loss"] = lr_.detach().numpy(), lf_.detach().numpy(), np.float64(loss.item())
+    for k, v in grads_to_np(disc).items():
+        out["g/" + k] = v
+    disc.zero_grad()
+    opt = torch.optim.Adam(disc.parameters())
+    ir = np.stack([rng.permutation(N)[:nb] for _ in range(steps)])
+    ih = np.stack([rng.permutation(N)[:nb] for _ in range(steps)])
+    curve = []
+    for s_ in range(steps):
+        opt.zero_grad()
+        a_, _ = disc(torch.from_numpy(real[ir[s_]]))
+        b_, _ = disc(torch.from_numpy(fake[ih[s_]]))
+        l_ = nn.BCEWithLogitsLoss()(a_, torch.ones_like(a_)) + nn.BCEWithLogitsLoss()(b_, torch.zeros_like(b_))
+        l_.backward()
+        opt.step()
+        curve.append(l_.item())
+    out["idx_real"], out["idx_fake"], out["curve"] = ir.astype(np.int64), ih.astype(np.int64), np.array(curve)
+    for k, v in sd_to_np(disc.state_dict()).items():
+        out["w_end/" + k] = v
+    out["meta"] = fu.pack_meta(dict(kind="posthoc_disc", N=N, T=T, dim=dim, nb=nb, steps=steps, hidden=50, layers=2))
+    np.savez_compressed(os.path.join(HERE, "posthoc_disc.npz"), **out)
+    # ---- predictor: column 2 one step ahead from the others
+    col = 2
+    torch.manual_seed(303)
+    pr = P.PosthocRNN(dim, int(dim / 2))
+    out = dict(fake=fake)
+    for k, v in sd_to_np(pr.state_dict()).items():
+        out["w/" + k] = v
+    g = torch.from_numpy(fake)
+
+    def xy(idx):
+        X = torch.cat((g[idx, :-1, :col], g[idx, :-1, col + 1:]), dim=2)
+        return X, g[idx, 1:, col].unsqueeze(-1)
+    X, Y = xy(np.arange(nb))
+    p_ = pr(X)
+    loss = nn.L1Loss()(p_, Y)
+    loss.backward()
+    out["pred"], out["loss"] = p_.detach().numpy(), np.float64(loss.item())
+    for k, v in grads_to_np(pr).items():
+        out["g/" + k] = v
+    pr.zero_grad()
+    opt = torch.optim.Adam(pr.parameters())
+    idx = np.stack([rng.permutation(N)[:nb] for _ in range(steps)])
+    curve = []
+    for s_ in range(steps):
+        X, Y = xy(idx[s_])
+        opt.zero_grad()
+        l_ = nn.L1Loss()(pr(X), Y)
+        l_.backward()
+        opt.step()
+        curve.append(l_.item())
+    out["idx"], out["curve"] = idx.astype(np.int64), np.array(curve)
+    for k, v in sd_to_np(pr.state_dict()).items():
+        out["w_end/" + k] = v
+    out["meta"] = fu.pack_meta(dict(kind="posthoc_pred", N=N, T=T, dim=dim, nb=nb, steps=steps, col=col))
+    np.savez_compressed(os.path.join(HERE, "posthoc_pred.npz"), **out)
+    print("posthoc_disc / posthoc_pred written")
+
+
 def schedule_case(DIFF):
     np.savez_compressed(os.path.join(HERE, "schedule.npz"), betas=DIFF.betas.numpy(), alphas=DIFF.alphas.numpy())
 
@@ -358,11 +447,14 @@ def schedule_case(DIFF):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'convert' / 'windows' / 'tvmcg': write only those fixtures (and the ones listed before them)")
+    ap.add_argument("--only", default="", help="'posthoc' / 'convert' / 'windows' / 'tvmcg': write only those fixtures (and the ones listed before them)")
     a = ap.parse_args()
     DIFF, VAE = import_reference(a.ref)
     import torch
     torch.set_num_threads(4)
+    posthoc_cases(a.ref)
+    if a.only == "posthoc":
+        return
     S = fu.SCHEMAS
     windows_case(a.ref, "windows_stride1", rows=60, F=8, seq_len=24, stride=1, B=16, seed=71)
     windows_case(a.ref, "windows_stride12", rows=131, F=13, seq_len=48, stride=12, B=5, seed=72)

@@ -89,3 +89,39 @@ def test_empty_shard_is_a_no_op_for_the_sequence_kernels():
     assert lib.tad_rnn_fwd(0, 0, 0, 0, 8, 24, 1, dirs, None) == 0
     bd = (_lib.RnnBwdDir * 1)()
     assert lib.tad_rnn_bwd(0, 0, 0, 0, 8, 24, 1, bd, None) == 0
+
+
+def test_vae_trainer_on_windowed_tables_equals_stacked_windows():
+    """response_train / cond_train as WindowedTable views of their tables (reference dataprovider_pypots.py:75-87 cuts
+    and stacks them; VAE.py:326-348 re-copies and indexes the stacked form every iteration): same losses and weights
+    as the trainer fed with the stacked tensors, on the same draws."""
+    import random
+    from timeautodiff_amd import VAE
+    from timeautodiff_amd.dataprovider_pypots import WindowedTable, sliding_window
+    g = torch.Generator().manual_seed(31)
+    rows, F, T, stride = 60, 6, 8, 2
+    table = torch.rand(rows, F, generator=g)
+    ctab = torch.rand(rows, F, generator=g) * 0.1
+    resp, cond = sliding_window(table, T, stride).cpu(), sliding_window(ctab, T, stride).cpu()
+    N = resp.shape[0]
+    mask = (torch.rand(N, T, F, generator=g) < 0.8).float()
+    val = dict(response_val=resp[:5], target_mask_val=mask[:5], cond_val=cond[:5])
+    runs = []
+    for windowed in (False, True):
+        torch.manual_seed(33)
+        random.seed(33)
+        ae = VAE.DeapStack(1, 0, 0, F, [], F, 24, 2, 16, 8, 6)
+        dd = dict(response_train=WindowedTable(table, T, stride) if windowed else resp, target_mask_train=mask,
+                  cond_train=WindowedTable(ctab, T, stride) if windowed else cond, **val)
+        tr = VAE.VAETrainer(ae, dd, batch_size=8, lr=1e-3, weight_decay=0.0, dtype="fp32", dev="cuda", graph=False)
+        assert tr.windowed == windowed and tr.N == N
+        eg = torch.Generator().manual_seed(35)
+        losses = [tr.train_step(0.1, eps=torch.randn(8, T, 6, generator=eg)) for _ in range(3)]
+        out, latent = tr.full_forward(eps=torch.randn(N, T, 6, generator=eg))
+        torch.cuda.synchronize()
+        runs.append((losses, tr.eng.fp.flat[:tr.eng.fp.n_active].cpu().clone(), latent.cpu().clone()))
+    assert max(abs(a - b) / abs(a) for a, b in zip(runs[0][0], runs[1][0])) < 2e-5
+    assert float((runs[0][1] - runs[1][1]).norm() / runs[0][1].norm()) < 1e-4
+    assert float((runs[0][2] - runs[1][2]).norm() / runs[0][2].norm()) < 1e-3
+    with pytest.raises(IndexError):
+        tr.train_step(0.1, idx=list(range(N - 7, N + 1)))

@@ -262,3 +262,57 @@ def test_tvmcg_corruption_matches_reference(name):
     # level / p of zero hand back the input itself
     assert otv.add_continuous_metadata_noise_subset(z["cond"], meta["cont_idx"], 0.0, None) is not None
     assert np.array_equal(otv.flip_categorical_metadata_subset(z["cond"], meta["cat_idx"], 0.0, classes, None, None), z["cond"])
+
+
+def test_posthoc_discriminator_matches_reference():
+    """Evaluation/Metrics.py:54-65, 91-109: logits, loss, every gradient and a 20-step Adam loss curve on recorded
+    minibatch indices."""
+    from oracle import posthoc
+    from oracle.optim import Adam
+    z, meta = fu.load("posthoc_disc")
+    sd = {k: v.copy() for k, v in fu.sub(z, "w").items()}
+    nb = meta["nb"]
+    loss, lr_, lf_, grads = posthoc.disc_loss_and_grads(sd, z["real"][:nb], z["fake"][:nb], meta["layers"])
+    assert fu.rel_err(lr_, z["logit_real"]) < TOL and fu.rel_err(lf_, z["logit_fake"]) < TOL
+    assert abs(loss - float(z["loss"])) < TOL * float(z["loss"])
+    gref = fu.sub(z, "g")
+    assert set(gref) == set(grads)
+    for k in gref:
+        assert fu.rel_err(grads[k].reshape(gref[k].shape), gref[k]) < 5e-5, k
+    opt = Adam(sd)
+    curve = []
+    for s in range(meta["steps"]):
+        l_, _, _, g_ = posthoc.disc_loss_and_grads(sd, z["real"][z["idx_real"][s]], z["fake"][z["idx_fake"][s]], meta["layers"])
+        opt.step({k: v.reshape(sd[k].shape) for k, v in g_.items()})
+        curve.append(l_)
+    assert np.max(np.abs(np.array(curve) - z["curve"]) / z["curve"]) < 1e-4
+    wend = fu.sub(z, "w_end")
+    for k in wend:
+        assert fu.rel_err(sd[k], wend[k]) < 1e-3, k
+
+
+def test_posthoc_predictor_matches_reference():
+    """Evaluation/predictive_metrics.py:8-17, 30-41: predictions, L1 loss, gradients, 20-step loss curve."""
+    from oracle import posthoc
+    from oracle.optim import Adam
+    z, meta = fu.load("posthoc_pred")
+    sd = {k: v.copy() for k, v in fu.sub(z, "w").items()}
+    nb, col, fake = meta["nb"], meta["col"], z["fake"]
+    others = [c for c in range(meta["dim"]) if c != col]
+
+    def xy(idx):
+        return fake[idx][:, :-1, others], fake[idx][:, 1:, col:col + 1]
+    X, Y = xy(np.arange(nb))
+    loss, p, grads = posthoc.pred_loss_and_grads(sd, X, Y)
+    assert fu.rel_err(p, z["pred"]) < TOL and abs(loss - float(z["loss"])) < TOL * float(z["loss"])
+    gref = fu.sub(z, "g")
+    for k in gref:
+        assert fu.rel_err(grads[k].reshape(gref[k].shape), gref[k]) < 5e-5, k
+    opt = Adam(sd)
+    curve = []
+    for s in range(meta["steps"]):
+        X, Y = xy(z["idx"][s])
+        l_, _, g_ = posthoc.pred_loss_and_grads(sd, X, Y)
+        opt.step({k: v.reshape(sd[k].shape) for k, v in g_.items()})
+        curve.append(l_)
+    assert np.max(np.abs(np.array(curve) - z["curve"]) / z["curve"]) < 1e-4

@@ -179,17 +179,37 @@ class VAETrainer:
         self.eng = eng = ae.engine(dev)
         d = eng.device
         f32 = dict(device=d, dtype=torch.float32)
-        n = lambda k: data_dict[k].to(**f32).contiguous() if data_dict.get(k) is not None else None  # noqa: E731
-        self.resp_tr, self.mask_tr, self.cond_tr = n("response_train"), n("target_mask_train"), n("cond_train")
+        from .dataprovider_pypots import WindowedTable
+        from .DIFF import _stage
+
+        def n(k, keep_windows=False):
+            v = data_dict.get(k)
+            if v is None:
+                return None
+            if isinstance(v, WindowedTable):
+                # training response / cond may stay un-materialised (windows are cut from the table per minibatch);
+                # everything else is small or needed whole
+                return _stage(v, d) if keep_windows else _stage(v, d).materialize()
+            return v.to(**f32).contiguous()
+        self.resp_tr, self.mask_tr, self.cond_tr = n("response_train", True), n("target_mask_train"), n("cond_train", True)
         self.resp_va, self.mask_va, self.cond_va = n("response_val"), n("target_mask_val"), n("cond_val")
+        self.windowed = isinstance(self.resp_tr, WindowedTable)
+        if self.cond_tr is not None and isinstance(self.cond_tr, WindowedTable) != self.windowed:
+            raise ValueError("response_train and cond_train must both be tensors or both be WindowedTable views")
         self.N, self.T, self.F = self.resp_tr.shape
+        if tuple(self.mask_tr.shape) != (self.N, self.T, self.F):
+            raise ValueError(f"target_mask_train has shape {tuple(self.mask_tr.shape)}, response_train {(self.N, self.T, self.F)}")
         self.B = batch_size
         self.lr, self.wd = lr, weight_decay
         self.plan = DataParallelPlan(batch_size, process_group)
-        # inp = response + cond, target = inp * mask (reference VAE.py:331-336), once, on device
-        self.inp_tr = torch.empty_like(self.resp_tr)
-        self.tgt_tr = torch.empty_like(self.resp_tr)
-        ops.vae_prepare(self.resp_tr, self.cond_tr, self.mask_tr, self.inp_tr, self.tgt_tr)
+        # inp = response + cond, target = inp * mask (reference VAE.py:331-336): once for the whole stacked set, or per
+        # minibatch when the set is a WindowedTable (the stacked form then never exists)
+        if self.windowed:
+            self.inp_tr = self.tgt_tr = None
+        else:
+            self.inp_tr = torch.empty_like(self.resp_tr)
+            self.tgt_tr = torch.empty_like(self.resp_tr)
+            ops.vae_prepare(self.resp_tr, self.cond_tr, self.mask_tr, self.inp_tr, self.tgt_tr)
         self.inp_va = torch.empty_like(self.resp_va)
         self.tgt_va = torch.empty_like(self.resp_va)
         ops.vae_prepare(self.resp_va, self.cond_va, self.mask_va, self.inp_va, self.tgt_va)
@@ -206,6 +226,7 @@ class VAETrainer:
         self.b_tgt = ws.get("batch.tgt", (nb, self.T, self.F))
         self.b_mask = ws.get("batch.mask", (nb, self.T, self.F))
         self.b_cond = ws.get("batch.cond", (nb, self.T, self.F)) if self.cond_tr is not None else None
+        self.b_resp = ws.get("batch.resp", (nb, self.T, self.F)) if self.windowed else None
         self.all_indices = list(range(self.N))
         self._next_idx = None
         # the validation pass works on a batch of another size: it gets a workspace of its own, so that neither pass
@@ -232,11 +253,17 @@ class VAETrainer:
 
     def _train_body(self, idx_d, eps_l, beta, captured=False):
         eng = self.eng
-        ops.gather_rows(self.inp_tr, idx_d, self.b_inp)
-        ops.gather_rows(self.tgt_tr, idx_d, self.b_tgt)
         ops.gather_rows(self.mask_tr, idx_d, self.b_mask)
-        if self.b_cond is not None:
-            ops.gather_rows(self.cond_tr, idx_d, self.b_cond)
+        if self.windowed:
+            self.resp_tr.gather_unchecked(idx_d, self.b_resp)          # indices come from a draw over range(N)
+            if self.b_cond is not None:
+                self.cond_tr.gather_unchecked(idx_d, self.b_cond)
+            ops.vae_prepare(self.b_resp, self.b_cond, self.b_mask, self.b_inp, self.b_tgt)
+        else:
+            ops.gather_rows(self.inp_tr, idx_d, self.b_inp)
+            ops.gather_rows(self.tgt_tr, idx_d, self.b_tgt)
+            if self.b_cond is not None:
+                ops.gather_rows(self.cond_tr, idx_d, self.b_cond)
         rows = self.B * self.T
         eng.fp.zero_grad()
         self.parts.zero_()
@@ -309,6 +336,8 @@ class VAETrainer:
             self._next_idx = None
         else:
             idx_d = torch.as_tensor(idx[lo:hi], dtype=torch.int64).to(d)
+            if idx_d.numel() and (int(idx_d.min()) < 0 or int(idx_d.max()) >= self.N):
+                raise IndexError("index out of range")          # the gathers below do not check
         if eps is None:
             eps = torch.randn(self.B, self.T, eng.lat, device=d)
         eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
@@ -363,9 +392,14 @@ class VAETrainer:
         d = eng.device
         if eps is None:
             eps = torch.randn(self.N, self.T, eng.lat, device=d)
-        z, mu, lv = eng.encoder(self.inp_tr, eps.to(device=d, dtype=torch.float32).contiguous(), train=False)
+        inp, cond = self.inp_tr, self.cond_tr
+        if self.windowed:               # the one place that needs the whole training set at once (reference VAE.py:395-402)
+            cond = self.cond_tr.materialize() if self.cond_tr is not None else None
+            inp = torch.empty(self.N, self.T, self.F, device=d)
+            ops.vae_prepare(self.resp_tr.materialize(), cond, self.mask_tr, inp, torch.empty_like(inp))
+        z, mu, lv = eng.encoder(inp, eps.to(device=d, dtype=torch.float32).contiguous(), train=False)
         latent = z.clone()
-        heads = eng.decoder(latent, self.mask_tr, self.cond_tr)
+        heads = eng.decoder(latent, self.mask_tr, cond)
         return eng.split_heads(heads, self.N, self.T), latent
 
 

@@ -524,6 +524,29 @@ extern "C" int tad_mse_loss(int64_t n, const float* pred, const float* target, f
   return TAD_OK;
 }
 
+// loss_sum[0] += sum |pred - target|; dpred = grad_scale * sign(pred - target) (0 where they are equal, as torch's L1Loss)
+__global__ void l1_loss_kernel(int64_t n, const float* __restrict__ pred, const float* __restrict__ target, float gs,
+                               float* __restrict__ dpred, float* __restrict__ loss_sum) {
+  float acc = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float d = pred[e] - target[e];
+    acc += fabsf(d);
+    if (dpred) dpred[e] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+  }
+  if (loss_sum) block_atomic_sum(acc, loss_sum);
+}
+
+extern "C" int tad_l1_loss(int64_t n, const float* pred, const float* target, float grad_scale, float* dpred, float* loss_sum,
+                           tad_stream_t stream) {
+  TAD_CHECK(n >= 0 && (n == 0 || (pred && target)), "tad_l1_loss: bad arguments");
+  if (n == 0) return TAD_OK;
+  unsigned g = ew_grid(n, 4);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(g), dim3(EW_BLOCK), 0, EW_STREAM, n, pred, target, grad_scale, dpred, loss_sum);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
 extern "C" int tad_grad_norm_sq(int64_t n, const float* g, float* out_sum, tad_stream_t stream) {
   TAD_CHECK(n >= 0 && out_sum && (n == 0 || g), "tad_grad_norm_sq: bad arguments");
   TAD_CHECK((reinterpret_cast<uintptr_t>(g) & 15) == 0, "tad_grad_norm_sq: the buffer must be 16-byte aligned");

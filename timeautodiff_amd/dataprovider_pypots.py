@@ -8,8 +8,9 @@ the stacked tensor is T times the table.  Here the table goes to the GPU once; a
 cut straight from it (``tad_gather_windows``: ``out[b, t, :] = table[idx[b] * stride + t, :]``).
 
 ``sliding_window`` keeps the reference's signature and result (the stacked tensor, built by one launch);
-``WindowedTable`` is the un-materialised form that ``DIFF.DiffusionTrainer`` and ``VAE.VAETrainer`` accept in
-place of an ``[N, T, F]`` tensor.
+``WindowedTable`` is the un-materialised form that ``DIFF.DiffusionTrainer`` accepts for ``time_info`` / ``cond`` and
+``VAE.VAETrainer`` for ``response_train`` / ``cond_train`` in place of an ``[N, T, F]`` tensor (masks stay stacked;
+validation sets are materialised once).
 """
 import torch
 

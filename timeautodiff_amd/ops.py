@@ -453,6 +453,13 @@ def mse_loss(pred, target, grad_scale, dpred, loss_sum):
           _stream())
 
 
+def l1_loss(pred, target, grad_scale, dpred, loss_sum):
+    """loss_sum[0] += sum |pred - target|; dpred = grad_scale * sign(pred - target) (all contiguous float32)."""
+    assert pred.is_contiguous() and target.is_contiguous() and pred.numel() == target.numel()
+    assert dpred is None or (dpred.is_contiguous() and dpred.numel() == pred.numel())
+    _call("tad_l1_loss", pred.numel(), _ptr(pred), _ptr(target), float(grad_scale), _ptr(dpred), _ptr(loss_sum), _stream())
+
+
 def grad_norm_sq(g, out_sum):
     """out_sum[0] += sum of squares of the contiguous float32 buffer g (one launch)."""
     assert g.is_contiguous() and g.dtype == torch.float32 and out_sum.dtype == torch.float32
