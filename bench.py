@@ -8,7 +8,11 @@ Workload (BASELINE.json configs[1]): energy_data-shaped windows (28 features = 1
 cardinality 8 + 27 numericals, T = 24, latent K = 6, denoiser H = 200, 2 layers, emb 128),
 bf16 matrix-core operands with fp32 accumulation and fp32 master weights.
 The "sampler" and "vae" objects of the JSON line carry the two companion rates (sampled sequences/s through
-all 100 reverse steps; VAE training samples/s).
+all 100 reverse steps; VAE training samples/s at the reference's hidden size 512, "vae_h200" at hidden 200).
+On one GPU the line also carries "extras": denoiser training at the other four workloads' shapes, the VAE at the
+Metro / AirQuality shapes, an fp32 line of the headline config (each with its own roofline object), and the
+reference-batch regime (B = 100) through DIFF.train_diffusion / VAE.train_autoencoder / DIFF.sample.
+`python bench.py --gpus N` started as ONE process launches its N ranks itself (fresh children, before any GPU call).
 A "step" is one full optimizer step of the denoiser (draws, gather, add_noise, forward, loss,
 backward, gradient all-reduce, Adam) on a per-GPU batch of 4096 windows (weak scaling: the
 global batch is 4096 x N).  The sampler line generates 1024 sequences per GPU through all 100
