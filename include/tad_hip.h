@@ -249,6 +249,11 @@ int tad_sampler_tail(int prec, int64_t rows, int D, int K, int H, const float* h
                      const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
                      float c1, float c2, float c3, int last, const float* w_in, const float* b_in, float* xh,
                      int64_t ldxh, tad_stream_t stream);
+/* The same launch with the next step's input projection written as bf16 (it feeds `proj`'s product only). */
+int tad_sampler_tail_b16(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
+                     const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
+                     float c1, float c2, float c3, int last, const float* w_in, const float* b_in, void* xh16,
+                     int64_t ldxh, tad_stream_t stream);
 
 /* Denoiser loss (DIFF.py:259-260) and its gradient: loss_sum[0] += sum (pred-target)^2,
  * dpred = grad_scale * (pred - target)  (grad_scale = 2/numel of the GLOBAL batch). */

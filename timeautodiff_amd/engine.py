@@ -746,6 +746,8 @@ class DenoiserEngine:
                            te2=self.imgs.add(p_("time_encode.2.weight"), fwd=True, tr=True))
             if self.time_dim % 8 == 0:
                 self.im["te0"] = self.imgs.add(p_("time_encode.0.weight"), fwd=True, tr=False)
+            # the sampler's per-step share of `proj`: its first H input columns (the input projection of x)
+            self.im["proj_x"] = self.imgs.add(p_("proj.net.0.weight")[:, :self.H], fwd=True, tr=False)
         self.ws = Workspace(device)
         # data parallel: the gradients of input_proj, t_enc, i_enc, proj, the LSTM, LayerNorm and fc occupy the head of
         # the flat buffer and are complete before the backward of the conditioning path starts: a trainer may reduce
@@ -1080,13 +1082,28 @@ class DenoiserEngine:
         fused = SAMPLE_FUSED_TAIL and ops.sampler_tail_supported(2 * H, K, H)
         if fused:       # the tail of every step leaves input_proj of the updated x behind; the first step needs it up front
             ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
+        # bf16 mode: what only the step's products read (the input projection, `proj`'s result) is kept as bf16
+        b16 = self.mm16 and fused
+        xh16 = pa16 = None
+        if b16:
+            self.imgs.pack()
+            xh16 = ws.get("s.xh16", (BT, H), dtype=torch.bfloat16)
+            pa16 = ws.get("s.pa16", (BT, H), dtype=torch.bfloat16)
+            ops.cvt_bf16(xh, xh16)
         return dict(x2=x2, B=B, T=T, ws=ws, pinv=pinv, V=V, wp=wp, z=z_all, xh=xh, pa=ws.get("pa", (BT, H)),
-                    ln=ws.get("ln", (BT, 2 * H)), pred=ws.get("pred", (BT, K)), fused=fused)
+                    ln=ws.get("ln", (BT, 2 * H)), pred=ws.get("pred", (BT, K)), fused=fused, b16=b16, xh16=xh16, pa16=pa16)
 
     def _sample_step(self, st, s, coef):
         """Reverse step s for the sequences of one ``_sample_setup`` state, on the current stream."""
         fp, prec, H = self.fp, self.prec, self.H
         x2, xh, pa, ln, pred = st["x2"], st["xh"], st["pa"], st["ln"], st["pred"]
+        if st["b16"]:
+            ops.mm16_nt(st["xh16"], self.im["proj_x"]["fwd"], st["V"][s], st["pa16"], act=ACT_RELU, residual=st["pinv"])
+            lout = self.lstm.forward(st["pa16"], st["B"], st["T"], st["ws"], "lstm", False)
+            ops.sampler_tail(prec, lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), fp.p("fc.weight"), fp.p("fc.bias"),
+                             x2, st["z"][s], coef[0][s], coef[1][s], coef[2][s], s == 0, fp.p("input_proj.net.0.weight"),
+                             fp.p("input_proj.net.0.bias"), st["xh16"])
+            return
         if not st["fused"]:
             ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
         ops.linear_fwd(prec, xh, st["wp"][:, :H], st["V"][s], pa, act=ACT_RELU, residual=st["pinv"])

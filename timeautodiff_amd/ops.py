@@ -571,11 +571,11 @@ def sampler_tail(prec, h, gamma, beta, fc_w, fc_b, x, z, c1, c2, c3, last, w_in,
     """LayerNorm(h) -> fc -> sampler update of x (in place, with noise z) -> xh = input_proj(updated x), one launch
     (reference DIFF.py:221-223, 348-351, 198)."""
     hp, rows, D, ldh = as2d(h)
-    xp, rows2, H, ldxh = as2d(xh)
+    xp, rows2, H, ldxh = as2d(xh, xh.dtype)
     K = fc_w.shape[0]
     assert rows == rows2 and fc_w.shape == (K, D) and w_in.shape == (H, K) and fc_w.is_contiguous() and w_in.is_contiguous()
     assert x.is_contiguous() and z.is_contiguous() and x.numel() == rows * K and z.numel() == rows * K
-    _call("tad_sampler_tail", prec, rows, D, K, H, hp, ldh, _ptr(gamma), _ptr(beta), float(eps), _ptr(fc_w), _ptr(fc_b), _ptr(x),
+    _call("tad_sampler_tail" + _sfx(xh), prec, rows, D, K, H, hp, ldh, _ptr(gamma), _ptr(beta), float(eps), _ptr(fc_w), _ptr(fc_b), _ptr(x),
           _ptr(z), float(c1), float(c2), float(c3), int(bool(last)), _ptr(w_in), _ptr(b_in), xp, ldxh, _stream())
 
 
