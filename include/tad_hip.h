@@ -309,6 +309,19 @@ int tad_silu_bwd(int64_t n, const float* z, const float* da, float* dz, tad_stre
 int tad_silu_fwd_b16(int64_t n, const float* z, void* a16, tad_stream_t stream);
 int tad_silu_bwd_b16(int64_t n, const float* z, const float* da, void* dz16, tad_stream_t stream);
 
+/* `layer_norm` + `fc` of BiRNN_score.forward (DIFF.py:221-223) in one pass over the recurrent output: LayerNorm of
+ * a row (eps 1e-5; mean_rstd[r] = {mean, rstd} for the backward), then pred[r, :] = fc_w [K, D] applied to it + fc_b
+ * (K <= 8, D <= 512).  The normalised row is written only if y != NULL.  prec = TAD_BF16 rounds the projection's
+ * operands to bf16 like the matrix kernels do. */
+int tad_ln_fc_fwd(int prec, int64_t rows, int D, int K, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                  float eps, const float* fc_w, const float* fc_b, float* y, int64_t ldy, float* mean_rstd, float* pred,
+                  tad_stream_t stream);
+/* ... and its autograd in one pass: the normalised row is recomputed from x and mean_rstd; dx [rows, D] =
+ * LayerNorm-backward(dpred fc_w); dgamma, dbeta, dfc_w [K, D], dfc_b [K] are accumulated into. */
+int tad_ln_fc_bwd(int prec, int64_t rows, int D, int K, const float* dpred, const float* x, int64_t ldx, const float* gamma,
+                  const float* beta, const float* mean_rstd, const float* fc_w, float* dx, int64_t lddx, float* dgamma,
+                  float* dbeta, float* dfc_w, float* dfc_b, tad_stream_t stream);
+
 /* nn.LayerNorm over the last dim D (DIFF.py:183, 221), eps 1e-5; mean_rstd[r] = {mean, rstd}. */
 int tad_layernorm_fwd(int64_t rows, int D, const float* x, int64_t ldx, const float* gamma, const float* beta,
                       float eps, float* y, int64_t ldy, float* mean_rstd, tad_stream_t stream);

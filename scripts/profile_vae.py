@@ -21,7 +21,8 @@ NV = 4 * bench.B_LOCAL
 ones = torch.ones(NV, bench.T, bench.F, device=dev)
 dd = dict(response_train=cond[:NV], target_mask_train=ones, cond_train=None,
           response_val=cond[NV:NV + 256], target_mask_val=ones[:256], cond_val=None)
-ae = DeapStack(1, 0, 1, 27, [8], bench.F, bench.H, 2, bench.E, 8, bench.K)
+HID = int(sys.argv[1]) if len(sys.argv) > 1 else bench.VAE_HIDDEN
+ae = DeapStack(1, 0, 1, 27, [8], bench.F, HID, 2, bench.E, 8, bench.K)
 vt = VAETrainer(ae, dd, batch_size=bench.B_LOCAL, lr=2e-4, weight_decay=1e-6, dtype="bf16", dev=dev)
 random.seed(99)
 for _ in range(3):

@@ -846,3 +846,38 @@ def test_grad_norm_sq(ops, dev, n):
     torch.cuda.synchronize()
     ref = 2.5 + float((g.double() ** 2).sum())
     assert abs(float(out.item()) - ref) < 1e-5 * ref
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("rows,D,K", [(7, 48, 6), (1000, 400, 6), (333, 400, 8), (64, 130, 3)])
+def test_ln_fc_fused_equals_the_separate_launches(ops, dev, prec, rows, D, K):
+    """LayerNorm + narrow projection in one launch, forward and backward, against layernorm_fwd/bwd + the linear family
+    (the same arithmetic per element; the sums of the gradients take another order: 1e-5 fp32; bf16 mode rounds the
+    projection's operands at the same points: 2e-3 on the weight gradient whose products it rounds)."""
+    g = torch.Generator(device=dev).manual_seed(rows + D + K)
+    x = torch.randn(rows, D, device=dev, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(D, device=dev, generator=g) + 0.5, torch.randn(D, device=dev, generator=g) * 0.1
+    W, b = torch.randn(K, D, device=dev, generator=g) * 0.1, torch.randn(K, device=dev, generator=g)
+    dpred = torch.randn(rows, K, device=dev, generator=g)
+    # separate launches
+    y, mr, pred = torch.empty(rows, D, device=dev), torch.empty(rows, 2, device=dev), torch.empty(rows, K, device=dev)
+    ops.layernorm_fwd(x, gamma, beta, y, mr)
+    ops.linear_fwd(prec, y, W, b, pred)
+    dy, dx = torch.empty(rows, D, device=dev), torch.empty(rows, D, device=dev)
+    dW, db, dga, dbe = (torch.zeros(K, D, device=dev), torch.zeros(K, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev))
+    ops.linear_bwd_data(prec, dpred, W, dy)
+    ops.linear_bwd_weight(prec, dpred, y, dW, db=db)
+    ops.layernorm_bwd(dy, x, gamma, mr, dx, dga, dbe)
+    # fused
+    mr2, pred2, y2 = torch.empty(rows, 2, device=dev), torch.empty(rows, K, device=dev), torch.empty(rows, D, device=dev)
+    ops.ln_fc_fwd(prec, x, gamma, beta, W, b, mr2, pred2, y=y2)
+    dx2 = torch.empty(rows, D, device=dev)
+    dW2, db2, dga2, dbe2 = (torch.full((K, D), 1.0, device=dev), torch.full((K,), 1.0, device=dev), torch.full((D,), 1.0, device=dev),
+                            torch.full((D,), 1.0, device=dev))                # accumulated into
+    ops.ln_fc_bwd(prec, dpred, x, gamma, beta, mr2, W, dx2, dga2, dbe2, dW2, db2)
+    torch.cuda.synchronize()
+    rel = lambda a, b_: float((a.double() - b_.double()).norm() / (b_.double().norm() + 1e-30))   # noqa: E731
+    tol = 1e-5 if prec == 0 else 2e-3
+    assert torch.equal(mr, mr2) and torch.equal(y, y2)
+    assert rel(pred2, pred) < tol and rel(dx2, dx) < tol
+    assert rel(dW2 - 1, dW) < tol and rel(db2 - 1, db) < 1e-5 and rel(dga2 - 1, dga) < tol and rel(dbe2 - 1, dbe) < tol

@@ -336,6 +336,190 @@ __global__ void sampler_tail_kernel(int64_t rows, int D, int K, int H, int round
   }
 }
 
+// LayerNorm followed by a narrow output projection (K <= 8 columns), one wave per row: the normalised row stays in
+// registers, the K outputs are K wave reductions.  Writes mean / rstd for the backward and, only if asked, the
+// normalised row.  round16: the projection's operands are rounded to bf16 where a bf16 matrix product would.
+template <int NC, int KMAX>
+__global__ __launch_bounds__(EW_BLOCK) void ln_fc_fwd_kernel(int64_t rows, int D, int K, int round16, const float* __restrict__ x, int64_t ldx,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                 const float* __restrict__ fcw, const float* __restrict__ fcb, float* __restrict__ y, int64_t ldy,
+                                 float* __restrict__ mr, float* __restrict__ pred) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float gm[NC], bt[NC], wk[KMAX][NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    gm[i] = c < D ? gamma[c] : 0.f;
+    bt[i] = c < D ? beta[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float w = (c < D && k < K) ? fcw[(int64_t)k * D + c] : 0.f;
+      wk[k][i] = round16 ? (float)(bf16_t)w : w;
+    }
+  }
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float* xr = x + r * ldx;
+    float xv[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = c < D ? xr[c] : 0.f;
+      if (c < D) s += xv[i];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const float dlt = xv[i] - mean;
+      if (lane + 64 * i < D) v += dlt * dlt;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      float yv = (xv[i] - mean) * rstd * gm[i] + bt[i];
+      if (y && c < D) y[r * ldy + c] = yv;
+      if (round16) yv = (float)(bf16_t)yv;
+      if (c >= D) yv = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) acc[k] += yv * wk[k][i];
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        const float p = wave_sum(acc[k]) + fcb[k];
+        if (lane == k) pred[r * K + k] = p;
+      }
+    }
+    if (lane == 0) { mr[2 * r] = mean; mr[2 * r + 1] = rstd; }
+  }
+}
+
+// Backward of the pair above, the normalised row recomputed from x and mean / rstd, as two launches over the rows
+// (one kernel, two roles; each keeps its column sums per lane over the wave's rows, combines them over the
+// workgroup's waves in LDS and adds them with one atomic per entry and workgroup):
+//   DW == false: d(row) = dpred W, LayerNorm's backward -> dx, dgamma, dbeta; many workgroups (it streams x in and
+//                dx out);
+//   DW == true:  the projection's weight gradient dW[k][c] += dpred[r][k] * y[r][c] and its bias gradient; few
+//                workgroups (K * D atomics each).
+// One launch doing both needs K * D / 64 more accumulators per lane than the register file gives at two waves per
+// SIMD, and its K + 2 atomics per column and workgroup cost more than the second pass over x.
+template <int NC, int KMAX, bool DW>
+__global__ __launch_bounds__(EW_BLOCK) void ln_fc_bwd_kernel(int64_t rows, int D, int K, int round16, const float* __restrict__ dpred,
+                                 const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ mr, const float* __restrict__ fcw,
+                                 float* __restrict__ dx, int64_t lddx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                 float* __restrict__ dfcw, float* __restrict__ dfcb) {
+  extern __shared__ float lnfc_red[];              // DW ? [KMAX][NC * 64] : [2][NC * 64]
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  constexpr int NA = DW ? KMAX : 2;
+  float acc[NA][NC], gm[NC], bt[NC], wk[DW ? 1 : KMAX][NC], dbk[KMAX];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    gm[i] = c < D ? gamma[c] : 0.f;
+    bt[i] = c < D ? beta[c] : 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc[a][i] = 0.f;
+    if constexpr (!DW) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const float w = (c < D && k < K) ? fcw[(int64_t)k * D + c] : 0.f;
+        wk[k][i] = round16 ? (float)(bf16_t)w : w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) dbk[k] = 0.f;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float mean = mr[2 * r], rstd = mr[2 * r + 1];
+    float dp[KMAX], dpq[KMAX];
+    const float mine = lane < K ? dpred[r * K + lane] : 0.f;      // one coalesced load of the row, then broadcasts
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      dp[k] = __shfl(mine, k, 64);
+      dpq[k] = round16 ? (float)(bf16_t)dp[k] : dp[k];
+      dbk[k] += dp[k];
+    }
+    float xh[NC], dxh[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      xh[i] = 0.f; dxh[i] = 0.f;
+      if (c < D) {
+        xh[i] = (x[r * ldx + c] - mean) * rstd;
+        if constexpr (DW) {
+          float yv = xh[i] * gm[i] + bt[i];
+          if (round16) yv = (float)(bf16_t)yv;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) acc[k][i] += dpq[k] * yv;
+        } else {
+          float g = 0.f;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) g += dpq[k] * wk[k][i];
+          dxh[i] = g * gm[i];
+          acc[0][i] += g * xh[i];
+          acc[1][i] += g;
+          s1 += dxh[i];
+          s2 += dxh[i] * xh[i];
+        }
+      }
+    }
+    if constexpr (!DW) {
+      const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) dx[r * lddx + c] = rstd * (dxh[i] - m1 - xh[i] * m2);
+      }
+    }
+  }
+  float* red = lnfc_red;
+  const int W = NC * 64;
+  for (int w = 0; w < nwb; ++w) {       // waves take turns adding their sums into the LDS rows
+    if (wib == w) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) red[a * W + c] = (w ? red[a * W + c] : 0.f) + acc[a][i];
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    if constexpr (DW) {
+      for (int k = 0; k < K; ++k) atomicAdd(&dfcw[(int64_t)k * D + c], red[k * W + c]);
+    } else {
+      atomicAdd(&dgamma[c], red[c]);
+      atomicAdd(&dbeta[c], red[W + c]);
+    }
+  }
+  if constexpr (DW) {
+    // the projection's bias gradient: every lane of a wave holds the same sums; combined over the workgroup's waves,
+    // one atomic per output and workgroup (the few workgroups of this role keep the traffic on these K addresses low)
+    __syncthreads();
+    if (lane == 0) {
+      for (int k = 0; k < K; ++k) red[wib * KMAX + k] = dbk[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+      float sum = 0.f;
+      for (int w = 0; w < nwb; ++w) sum += red[w * KMAX + threadIdx.x];
+      atomicAdd(&dfcb[threadIdx.x], sum);
+    }
+  }
+}
+
 // One wave per row.  The column sums (dgamma, dbeta) are kept per lane over the wave's rows, combined over
 // the workgroup's waves in LDS, and added to the result with one atomic per column and workgroup.
 template <int NC>
@@ -749,6 +933,45 @@ extern "C" int tad_layernorm_bwd(int64_t rows, int D, const float* dy, int64_t l
   else if (nc <= 16) LN_BWD(16);
   else LN_BWD(32);
 #undef LN_BWD
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_ln_fc_fwd(int prec, int64_t rows, int D, int K, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                             float eps, const float* fc_w, const float* fc_b, float* y, int64_t ldy, float* mean_rstd, float* pred,
+                             tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && D > 0 && D <= 512 && K > 0 && K <= 8, "tad_ln_fc_fwd: supported D <= 512, K <= 8 (got D=%d K=%d)", D, K);
+  TAD_CHECK(x && gamma && beta && fc_w && fc_b && mean_rstd && pred && ldx >= D && (!y || ldy >= D), "tad_ln_fc_fwd: bad arguments");
+  if (rows == 0) return TAD_OK;
+  int64_t g = cdiv64(rows, EW_BLOCK / 64);
+  if (g > 2048) g = 2048;
+  const int r16 = prec == TAD_BF16 ? 1 : 0;
+#define LNFC(NC) hipLaunchKernelGGL((ln_fc_fwd_kernel<NC, 8>), dim3((unsigned)g), dim3(EW_BLOCK), 0, EW_STREAM, rows, D, K, r16, x, ldx, gamma, beta, eps, fc_w, fc_b, y, ldy, mean_rstd, pred)
+  if (D <= 128) LNFC(2);
+  else LNFC(8);
+#undef LNFC
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_ln_fc_bwd(int prec, int64_t rows, int D, int K, const float* dpred, const float* x, int64_t ldx, const float* gamma,
+                             const float* beta, const float* mean_rstd, const float* fc_w, float* dx, int64_t lddx, float* dgamma,
+                             float* dbeta, float* dfc_w, float* dfc_b, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && D > 0 && D <= 512 && K > 0 && K <= 8, "tad_ln_fc_bwd: supported D <= 512, K <= 8 (got D=%d K=%d)", D, K);
+  TAD_CHECK(dpred && x && gamma && beta && mean_rstd && fc_w && dx && dgamma && dbeta && dfc_w && dfc_b && ldx >= D && lddx >= D,
+            "tad_ln_fc_bwd: bad arguments");
+  if (rows == 0) return TAD_OK;
+  static const char* cap_env = getenv("TAD_LNFC_BWD_GRID");     // experiments: workgroups of the two launches
+  static const char* cap2_env = getenv("TAD_LNFC_DW_GRID");
+  int64_t g = cdiv64(rows, EW_BLOCK / 64), g2 = g;
+  const int64_t cap = cap_env ? atoi(cap_env) : 1536, cap2 = cap2_env ? atoi(cap2_env) : 768;     // measured at 98 304 x 400: 246 us; (1536, 256) 390, (1024, 1024) 316
+  if (g > cap) g = cap;
+  if (g2 > cap2) g2 = cap2;
+  const int r16 = prec == TAD_BF16 ? 1 : 0;
+#define LNFC(NC, DWV, G, NAV) hipLaunchKernelGGL((ln_fc_bwd_kernel<NC, 8, DWV>), dim3((unsigned)(G)), dim3(EW_BLOCK), sizeof(float) * (NAV) * NC * 64, EW_STREAM, rows, D, K, r16, dpred, x, ldx, gamma, beta, mean_rstd, fc_w, dx, lddx, dgamma, dbeta, dfc_w, dfc_b)
+  if (D <= 128) { LNFC(2, false, g, 2); LNFC(2, true, g2, 8); }
+  else { LNFC(8, false, g, 2); LNFC(8, true, g2, 8); }
+#undef LNFC
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

@@ -27,6 +27,8 @@ SIDE_PRIORITY = int(os.environ.get("TAD_SIDE_PRIORITY", "0"))
 # TAD_MM16=0: bf16 precision keeps every activation in fp32 and uses the fp32-operand product kernels throughout
 # (the path of the fp32 mode with operands rounded inside the kernels; experiments and A/B timing)
 MM16 = os.environ.get("TAD_MM16", "1") != "0"
+# TAD_LN_FC_FUSED=0: layer_norm and fc of the denoiser as separate launches (forward and backward)
+LN_FC_FUSED = os.environ.get("TAD_LN_FC_FUSED", "1") != "0"
 
 
 def prec_of(dtype):
@@ -803,12 +805,37 @@ class DenoiserEngine:
         pa = ws.get("pa", (BT, H))
         ops.linear_fwd(prec, cat, fp.p("proj.net.0.weight"), fp.p("proj.net.0.bias"), pa, act=ACT_RELU)
         lout = self.lstm.forward(pa, B, T, ws, "lstm", train)
-        ln = ws.get("ln", (BT, 2 * H))
+        return self._ln_fc(lout, BT, train).view(B, T, K)
+
+    def _ln_fc(self, lout, BT, train):
+        """layer_norm + fc (reference DIFF.py:221-223): one launch that keeps the normalised row in registers where the
+        widths allow (the backward recomputes it), else LayerNorm and the projection as two."""
+        fp, ws, prec, H, K = self.fp, self.ws, self.prec, self.H, self.K
         mr = ws.get("mr", (BT, 2))
-        ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, mr)
         pred = ws.get("pred", (BT, K))
-        ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
-        return pred.view(B, T, K)
+        self._lnfc = LN_FC_FUSED and ops.ln_fc_supported(2 * H, K)
+        if self._lnfc:
+            ops.ln_fc_fwd(prec, lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), fp.p("fc.weight"), fp.p("fc.bias"), mr, pred)
+        else:
+            ln = ws.get("ln", (BT, 2 * H))
+            ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, mr)
+            ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
+        return pred
+
+    def _ln_fc_bwd(self, dpred, lout, BT):
+        """-> d(loss)/d(recurrent output); the gradients of layer_norm and fc are accumulated."""
+        fp, ws, prec, H = self.fp, self.ws, self.prec, self.H
+        mr = ws.get("mr", (BT, 2))
+        dlout = ws.get("dlout", (BT, 2 * H))
+        if self._lnfc:
+            ops.ln_fc_bwd(prec, dpred, lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), mr, fp.p("fc.weight"), dlout,
+                          fp.g("layer_norm.weight"), fp.g("layer_norm.bias"), fp.g("fc.weight"), fp.g("fc.bias"))
+        else:
+            ln = ws.get("ln", (BT, 2 * H))
+            dln = ws.get("dln", (BT, 2 * H))
+            _lin_bwd(fp, prec, dpred, ln, fp.p("fc.weight"), fp.g("fc.weight"), fp.g("fc.bias"), dx=dln)
+            ops.layernorm_bwd(dln, lout, fp.p("layer_norm.weight"), mr, dlout, fp.g("layer_norm.weight"), fp.g("layer_norm.bias"))
+        return dlout
 
     def _forward16(self, x2, t1, i1, ti2, c2, B, T):
         """The training forward with every tensor that only matrix products read kept as bfloat16: the products
@@ -833,12 +860,7 @@ class DenoiserEngine:
         pa = ws.get("pa16", (BT, H), dtype=b16)
         ops.mm16_nt(cat, im["proj"]["fwd"], fp.p("proj.net.0.bias"), pa, act=ACT_RELU)
         lout = self.lstm.forward(pa, B, T, ws, "lstm", True)
-        ln = ws.get("ln", (BT, 2 * H))
-        mr = ws.get("mr", (BT, 2))
-        ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, mr)
-        pred = ws.get("pred", (BT, K))
-        ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
-        return pred.view(B, T, K)
+        return self._ln_fc(lout, BT, True).view(B, T, K)
 
     def _encodings16(self, cat, ta, t1, i1, ti2, BT):
         fp, ws, prec, H, im = self.fp, self.ws, self.prec, self.H, self.im
@@ -879,14 +901,9 @@ class DenoiserEngine:
         cat = ws.get("cat", (BT, 4 * H))
         ta = ws.get("ta", (BT, H))
         pa = ws.get("pa", (BT, H))
-        ln = ws.get("ln", (BT, 2 * H))
-        mr = ws.get("mr", (BT, 2))
         lout = ws.get("lstm.out%d" % (self.L - 1), (BT, 2 * H))
         gout = ws.get("gru.out%d" % (self.L - 1), (BT, 2 * H))
-        dln = ws.get("dln", (BT, 2 * H))
-        _lin_bwd(fp, prec, dpred, ln, fp.p("fc.weight"), fp.g("fc.weight"), fp.g("fc.bias"), dx=dln)
-        dlout = ws.get("dlout", (BT, 2 * H))
-        ops.layernorm_bwd(dln, lout, fp.p("layer_norm.weight"), mr, dlout, fp.g("layer_norm.weight"), fp.g("layer_norm.bias"))
+        dlout = self._ln_fc_bwd(dpred, lout, BT)
         dpz = self.lstm.backward(dlout, ws, "lstm", need_dx=True, relu_of=pa)      # includes the ReLU of proj
         dcat = ws.get("dcat", (BT, 4 * H))
         _lin_bwd(fp, prec, dpz, cat, fp.p("proj.net.0.weight"), fp.g("proj.net.0.weight"), fp.g("proj.net.0.bias"), dx=dcat)
@@ -918,14 +935,9 @@ class DenoiserEngine:
         cat = ws.get("cat16", (BT, 4 * H), dtype=b16)
         ta = ws.get("ta16", (BT, H), dtype=b16)
         pa = ws.get("pa16", (BT, H), dtype=b16)
-        ln = ws.get("ln", (BT, 2 * H))
-        mr = ws.get("mr", (BT, 2))
         lout = ws.get("lstm.out%d" % (self.L - 1), (BT, 2 * H))
         gout16 = self.gru.out16[self.L - 1]
-        dln = ws.get("dln", (BT, 2 * H))
-        _lin_bwd(fp, prec, dpred, ln, fp.p("fc.weight"), fp.g("fc.weight"), fp.g("fc.bias"), dx=dln)
-        dlout = ws.get("dlout", (BT, 2 * H))
-        ops.layernorm_bwd(dln, lout, fp.p("layer_norm.weight"), mr, dlout, fp.g("layer_norm.weight"), fp.g("layer_norm.bias"))
+        dlout = self._ln_fc_bwd(dpred, lout, BT)
         dpa = self.lstm.backward(dlout, ws, "lstm", need_dx=True)
         dpz = ws.get("dpz16", (BT, H), dtype=b16)
         ops.cvt_bf16(dpa, dpz, relu_of=pa)                                  # the ReLU of proj

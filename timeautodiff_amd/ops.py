@@ -514,6 +514,31 @@ def layernorm_fwd(x, gamma, beta, y, mean_rstd, eps=1e-5):
     _call("tad_layernorm_fwd", rows, D, xp, ldx, gamma.data_ptr(), beta.data_ptr(), float(eps), yp, ldy, _ptr(mean_rstd), _stream())
 
 
+def ln_fc_supported(D, K):
+    return D <= 512 and K <= 8
+
+
+def ln_fc_fwd(prec, x, gamma, beta, fc_w, fc_b, mean_rstd, pred, y=None, eps=1e-5):
+    """pred = fc(LayerNorm(x)) in one launch (K = fc_w.shape[0] <= 8 outputs per row); y receives the normalised rows
+    only if given."""
+    xp, rows, D, ldx = as2d(x)
+    K = fc_w.shape[0]
+    assert fc_w.shape == (K, D) and fc_w.is_contiguous() and pred.is_contiguous() and pred.numel() == rows * K
+    yp, ldy = (None, 0) if y is None else (as2d(y)[0], as2d(y)[3])
+    _call("tad_ln_fc_fwd", prec, rows, D, K, xp, ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(fc_w), _ptr(fc_b), yp, ldy,
+          _ptr(mean_rstd), _ptr(pred), _stream(), cost=(2.0 * rows * D * K, 4.0 * rows * (D + K + 2)))
+
+
+def ln_fc_bwd(prec, dpred, x, gamma, beta, mean_rstd, fc_w, dx, dgamma, dbeta, dfc_w, dfc_b):
+    """Backward of ln_fc_fwd in one launch: dx, and += into dgamma, dbeta, dfc_w, dfc_b."""
+    xp, rows, D, ldx = as2d(x)
+    dxp, rows2, D2, lddx = as2d(dx)
+    K = fc_w.shape[0]
+    assert rows == rows2 and D == D2 and dpred.is_contiguous() and dpred.numel() == rows * K and dfc_w.is_contiguous()
+    _call("tad_ln_fc_bwd", prec, rows, D, K, _ptr(dpred), xp, ldx, _ptr(gamma), _ptr(beta), _ptr(mean_rstd), _ptr(fc_w), dxp, lddx,
+          _ptr(dgamma), _ptr(dbeta), _ptr(dfc_w), _ptr(dfc_b), _stream(), cost=(4.0 * rows * D * K, 4.0 * rows * (2 * D + K + 2)))
+
+
 def layernorm_bwd(dy, x, gamma, mean_rstd, dx, dgamma, dbeta):
     dyp, rows, D, lddy = as2d(dy)
     xp, _, _, ldx = as2d(x)
