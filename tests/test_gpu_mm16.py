@@ -151,4 +151,25 @@ def test_mm16_tn_accumulates_and_rejects(ops, dev):
     with pytest.raises((RuntimeError, AssertionError)):
         ops.mm16_tn(A, [dict(b=B[:, :4], c=C[:, :4].contiguous())])     # nb not a multiple of 8
     with pytest.raises((RuntimeError, AssertionError, IndexError)):
-        ops.mm16_tn(A, [dict(b=B, c=C)] * 5)                            # more than four jobs
+        ops.mm16_tn(A, [dict(b=B, c=C)] * 9)                            # more than eight jobs
+
+
+def test_mm16_tn_jobs_with_their_own_a_operands(ops, dev):
+    """Eight small products of different layers (different A operands and widths, the same number of rows) in one
+    launch, as the backward pass queues them; one job still uses the shared operand."""
+    M = 3000
+    g = torch.Generator(device=dev).manual_seed(77)
+    shared = torch.randn(M, 48, device=dev, generator=g).bfloat16()
+    jobs, refs = [], []
+    for k, (na, nb) in enumerate([(200, 800), (200, 200), (128, 128), (128, 560), (432, 432), (96, 96), (8, 8), (48, 24)]):
+        A = shared if k == 7 else torch.randn(M, na + 8, device=dev, generator=g).bfloat16()
+        B = torch.randn(M, nb, device=dev, generator=g).bfloat16()
+        c, db = torch.zeros(na, nb, device=dev), torch.zeros(na, device=dev)
+        jobs.append(dict(b=B, c=c, db=db, a0=0, na=na, **({} if k == 7 else dict(a=A))))
+        refs.append((A[:, :na].double().T @ B.double(), A[:, :na].double().sum(0)))
+    ops.mm16_tn(shared, jobs)
+    torch.cuda.synchronize()
+    for j, (rc, rb) in zip(jobs, refs):
+        assert _rel(j["c"], rc) < 2e-5 and _rel(j["db"], rb) < 2e-5
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.mm16_tn(None, [dict(b=jobs[0]["b"], c=jobs[0]["c"])])          # no A operand at all

@@ -33,7 +33,7 @@ class RnnBwdDir(C.Structure):
 
 class TnJob(C.Structure):
     _fields_ = [("B16", _p), ("ldb", _i64), ("nb", _i64), ("shift", _i64), ("C", _p), ("ldc", _i64), ("db", _p), ("db2", _p),
-                ("a0", _i64), ("na", _i64), ("gate_map", C.c_int32 * 6)]
+                ("a0", _i64), ("na", _i64), ("gate_map", C.c_int32 * 6), ("A16", _p), ("lda", _i64)]
 
 
 class PackW16Job(C.Structure):

@@ -464,7 +464,7 @@ int launch_nt(NtParams& p, hipStream_t s) {
 // the tile (2 x 4 MFMA blocks) and skips the 32-column blocks of B beyond the operand.  For the recurrent layers
 // (B = x or h_{t-1}, at most 256 wide per tile) a column of the gate gradients is fetched into LDS by one workgroup
 // only.  Stage = 32 reduction rows: A image [32][256] + B image [32][256] bf16 (32 KiB); 4 stages, three in flight.
-constexpr int TN_MAXJOBS = 4;
+constexpr int TN_MAXJOBS = 8;
 constexpr int TN_BK = 32;                      // reduction rows per stage
 constexpr int TN_TA = 256, TN_TB = 256;        // tile: columns of A, columns of B
 constexpr int TN_IMG = TN_BK * 512;            // bytes of one image: [32 rows][256 columns] bf16
@@ -472,6 +472,7 @@ constexpr int TN_STAGE = 2 * TN_IMG;
 constexpr int TN_ST = 4;
 
 struct TnJob {
+  const bf16_t* A; int64_t lda;                            // this job's A operand [M, lda]
   const bf16_t* B; int64_t ldb; int nb; int shift;       // B [M, nb]; rows read at m + shift inside windows of T rows
   float* C; int64_t ldc;                                   // C [na', nb] += ..., na' = rows after the gate map
   float* db; float* db2;                                   // += column sums of A (NULL: none)
@@ -480,7 +481,7 @@ struct TnJob {
   int tiles_a, tiles_b, tile_base;
 };
 struct TnParams {
-  const bf16_t* A; int64_t lda; int64_t M; int T;
+  int64_t M; int T;
   TnJob job[TN_MAXJOBS]; int njobs;
   int tiles_total, nsplits; int64_t rows_per_split, nitems; int dbg;
 };
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
     ca[j] = a_c0 + 8 * fch; if (ca[j] > a_end - 8) ca[j] = a_end - 8;     // beyond the range: any readable column (feeds rows / columns nobody stores)
     cb[j] = b_c0 + 8 * fch; if (cb[j] > b_end - 8) cb[j] = b_end - 8;
   }
-  const unsigned char* const abase = reinterpret_cast<const unsigned char*>(p.A);
+  const unsigned char* const abase = reinterpret_cast<const unsigned char*>(J.A);
   const unsigned char* const bbase = reinterpret_cast<const unsigned char*>(J.B);
   const int T = p.T, shift = J.shift;
   int tpos[2];                                                      // time position of this lane's rows (only with a shift)
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
     for (int j = 0; j < 2; ++j) {
       const int64_t m = m0 + 2 * (2 * wave + j) + fsub;
       const bool okm = live && m < m_end;
-      const unsigned char* sa = okm ? abase + 2 * (m * p.lda + ca[j]) : zero;
+      const unsigned char* sa = okm ? abase + 2 * (m * J.lda + ca[j]) : zero;
       glds16(sa, st + j * 1024);
       bool okb = okm;
       if (T > 0) okb = okb && (unsigned)(tpos[j] + shift) < (unsigned)T;
@@ -734,18 +735,22 @@ extern "C" int tad_mm16_tn(int64_t M, int64_t T, const void* A16, int64_t lda, i
   TAD_CHECK(M >= 0 && M < (1ll << 31) && T >= 0 && T < (1 << 30) && (T == 0 || M % T == 0), "tad_mm16_tn: bad M=%ld T=%ld", (long)M, (long)T);
   TAD_CHECK(jobs && njobs >= 1 && njobs <= TN_MAXJOBS, "tad_mm16_tn: 1..%d jobs", TN_MAXJOBS);
   if (M == 0) return TAD_OK;                   // an empty batch adds nothing
-  TAD_CHECK(A16 && al16(A16) && lda % 8 == 0 && lda < (1 << 22), "tad_mm16_tn: A16 needs 16-byte aligned rows (lda %% 8 == 0)");
+  TAD_CHECK(!A16 || (al16(A16) && lda % 8 == 0 && lda < (1 << 22)), "tad_mm16_tn: A16 needs 16-byte aligned rows (lda %% 8 == 0)");
   TnParams p{};
-  p.A = reinterpret_cast<const bf16_t*>(A16); p.lda = lda; p.M = M; p.T = (int)T; p.njobs = njobs;
+  p.M = M; p.T = (int)T; p.njobs = njobs;
   int tiles = 0;
   for (int k = 0; k < njobs; ++k) {
     const tad_mm16_tn_job_t& u = jobs[k];
     TAD_CHECK(u.B16 && u.C && al16(u.B16) && u.ldb % 8 == 0 && u.ldb < (1 << 22) && u.nb >= 8 && u.nb % 8 == 0 && u.ldb >= u.nb,
               "tad_mm16_tn: job %d: B16 needs 16-byte aligned rows, nb a multiple of 8", k);
-    TAD_CHECK(u.a0 >= 0 && u.na >= 8 && u.a0 % 8 == 0 && u.na % 8 == 0 && u.a0 + u.na <= lda, "tad_mm16_tn: job %d: bad A column range", k);
+    const void* ja = u.A16 ? u.A16 : A16;
+    const int64_t jlda = u.A16 ? u.lda : lda;
+    TAD_CHECK(ja && al16(ja) && jlda % 8 == 0 && jlda < (1 << 22), "tad_mm16_tn: job %d: no A operand, or rows not 16-byte aligned", k);
+    TAD_CHECK(u.a0 >= 0 && u.na >= 8 && u.a0 % 8 == 0 && u.na % 8 == 0 && u.a0 + u.na <= jlda, "tad_mm16_tn: job %d: bad A column range", k);
     TAD_CHECK(u.ldc >= u.nb && (T > 0 || u.shift == 0) && u.shift > -(T > 0 ? T : 1) && u.shift < (T > 0 ? T : 1), "tad_mm16_tn: job %d: bad ldc / shift", k);
     TAD_CHECK(u.db || !u.db2, "tad_mm16_tn: job %d: db2 without db", k);
     TnJob& j = p.job[k];
+    j.A = reinterpret_cast<const bf16_t*>(ja); j.lda = jlda;
     j.B = reinterpret_cast<const bf16_t*>(u.B16); j.ldb = u.ldb; j.nb = (int)u.nb; j.shift = (int)u.shift;
     j.C = u.C; j.ldc = u.ldc; j.db = u.db; j.db2 = u.db2; j.a0 = (int)u.a0; j.na = (int)u.na;
     j.mapH = 0;

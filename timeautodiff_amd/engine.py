@@ -89,6 +89,7 @@ class FlatParams:
         self._join_ev = torch.cuda.Event() if self.side is not None else None
         self._side_busy = False
         self._queued = []
+        self._tn_jobs = []
         for name, p in params.items():
             view = self.p(name)
             view.copy_(p.data.to(device=device, dtype=torch.float32))
@@ -149,6 +150,20 @@ class FlatParams:
             return fn(*args, **kwargs)
         self._queued.append((fn, args, kwargs))
 
+    def queue_tn(self, a16, job):
+        """Queue one small weight-gradient product (ops.mm16_tn job with its own A operand).  The products of a
+        backward pass that are queued this way leave together at ``flush_tn`` -- one launch per eight jobs, in which
+        every job gets a share of the chip and a dozen reduction splits instead of a launch of its own with hundreds."""
+        j = dict(job)
+        j["a"] = a16
+        self._tn_jobs.append(j)
+
+    def flush_tn(self):
+        """Launch the queued weight-gradient products (deferred to the gradient stream like every weight gradient)."""
+        jobs, self._tn_jobs = self._tn_jobs, []
+        for i in range(0, len(jobs), 8):
+            self.defer(ops.mm16_tn, None, jobs[i:i + 8])
+
     def release(self):
         """Issue the queued launches on the side stream; called right before a latency-bound kernel goes to the
         current stream, so that the two run side by side."""
@@ -164,6 +179,8 @@ class FlatParams:
 
     def join(self):
         """Issue what is still queued; the current stream then waits for everything deferred so far."""
+        if self._tn_jobs:
+            self.flush_tn()
         self.release()
         if self._side_busy:
             self._join_ev.record(self.side)
@@ -670,14 +687,14 @@ class EmbBlock:
                 ops.cvt_bf16(dout, d16)
                 dout = d16
             ops.mm16_nt(dout, im["o2"]["tr"], None, da2, relu_of=a2)
-            fp.defer(ops.mm16_tn, dout, [dict(b=a2, c=gw2, db=gb2)])
+            fp.queue_tn(dout, dict(b=a2, c=gw2, db=gb2))
         else:
             a2 = ws.get(f"{tag}.a2", (rows, E))
             da2f = ws.get(f"{tag}.da2", (rows, E))
             ops.linear_bwd_data(prec, dout, fp.p(pre + "mlp_output.2.weight"), da2f, relu_of=a2)
             fp.defer(ops.linear_bwd_weight, prec, dout, a2, gw2, db=gb2)
             ops.cvt_bf16(da2f, da2)
-        fp.defer(ops.mm16_tn, da2, [dict(b=ecat, c=fp.g(pre + "mlp_output.0.weight"), db=fp.g(pre + "mlp_output.0.bias"))])
+        fp.queue_tn(da2, dict(b=ecat, c=fp.g(pre + "mlp_output.0.weight"), db=fp.g(pre + "mlp_output.0.bias")))
         wt = im["o0"]["tr"]                       # [cat_dim, E]: rows = columns of ecat
         if nd:
             # the table gradients sum these values element by element: float32
@@ -693,10 +710,10 @@ class EmbBlock:
             ops.mm16_nt(da2, img_rows(wt, nd * E, 16 * nn), None, dy1)
             da1 = ws.get(f"{tag}.da1", (rows, 16 * nn))
             ops.mm16_nt(dy1, im["n2"]["tr"], None, da1)
-            fp.defer(ops.mm16_tn, dy1, [dict(b=a1, c=fp.g(pre + "mlp_nums.2.weight"), db=fp.g(pre + "mlp_nums.2.bias"))])
+            fp.queue_tn(dy1, dict(b=a1, c=fp.g(pre + "mlp_nums.2.weight"), db=fp.g(pre + "mlp_nums.2.bias")))
             dz1 = ws.get(f"{tag}.dz1_16", (rows, 16 * nn), dtype=b16)
             ops.silu_bwd(z1, da1, dz1)
-            fp.defer(ops.mm16_tn, dz1, [dict(b=feats, c=fp.g(pre + "mlp_nums.0.weight"), db=fp.g(pre + "mlp_nums.0.bias"))])
+            fp.queue_tn(dz1, dict(b=feats, c=fp.g(pre + "mlp_nums.0.weight"), db=fp.g(pre + "mlp_nums.0.bias")))
 
 
 def _lin_bwd(fp, prec, dy, x, w, gw, gb, dx=None, relu_of=None, accumulate=False):
@@ -941,7 +958,7 @@ class DenoiserEngine:
         dpa = self.lstm.backward(dlout, ws, "lstm", need_dx=True)
         dpz = ws.get("dpz16", (BT, H), dtype=b16)
         ops.cvt_bf16(dpa, dpz, relu_of=pa)                                  # the ReLU of proj
-        fp.defer(ops.mm16_tn, dpz, [dict(b=cat, c=fp.g("proj.net.0.weight"), db=fp.g("proj.net.0.bias"))])
+        fp.queue_tn(dpz, dict(b=cat, c=fp.g("proj.net.0.weight"), db=fp.g("proj.net.0.bias")))
         # d(cat) in three pieces of proj's transposed image: the input-projection / cond_output share and the
         # time-encoding share feed matrix products only (bf16); the t / step encodings' share is summed column by
         # column (their weight and bias gradients): float32
@@ -958,14 +975,15 @@ class DenoiserEngine:
         fp.defer(ops.colsum, denc[:, H:H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
                  out_wsum=fp.g("i_enc.linear_proj.weight"))
         if self.on_first_bucket is not None:
+            fp.flush_tn()                   # proj's weight gradient is among the queued products: it belongs to this bucket
             self.on_first_bucket()          # gradients of input_proj .. fc (the head of the flat buffer) are all enqueued
         dta = ws.get("dta16", (BT, H), dtype=b16)
         ops.mm16_nt(dtenc, im["te2"]["tr"], None, dta, relu_of=ta)
-        fp.defer(ops.mm16_tn, dtenc, [dict(b=ta, c=fp.g("time_encode.2.weight"), db=fp.g("time_encode.2.bias"))])
+        fp.queue_tn(dtenc, dict(b=ta, c=fp.g("time_encode.2.weight"), db=fp.g("time_encode.2.bias")))
         fp.defer(ops.linear_bwd_weight, prec, dta, ti2, fp.g("time_encode.0.weight"), db=fp.g("time_encode.0.bias"))
         dgout = ws.get("dgout", (BT, 2 * H))
         ops.mm16_nt(dxh, im["co"]["tr"], None, dgout)
-        fp.defer(ops.mm16_tn, dxh, [dict(b=gout16, c=fp.g("cond_output.weight"), db=fp.g("cond_output.bias"))])
+        fp.queue_tn(dxh, dict(b=gout16, c=fp.g("cond_output.weight"), db=fp.g("cond_output.bias")))
         demb = self.gru.backward(dgout, ws, "gru", need_dx=True)
         self.emb.backward(demb, ws, "emb")
         fp.join()

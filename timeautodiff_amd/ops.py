@@ -295,29 +295,42 @@ def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=
 
 
 def mm16_tn(a16, jobs, T=0):
-    """Weight gradients from bf16-stored operands, one launch for all ``jobs`` (they share a16 [M, lda]):
-    job = dict(b=bfloat16 [M, nb], c=float32 [rows, nb] (accumulated into), a0=0, na=None (columns of a16), shift=0,
-    db=None, db2=None, gate_map=None).  c += a16[:, a0:a0+na]^T b', b' = b with rows shifted by ``shift`` inside windows
-    of T rows (zeros outside the window)."""
-    ap, M, Na, lda = as2d(a16, torch.bfloat16)
+    """Weight gradients from bf16-stored operands, one launch for all ``jobs`` (at most 8):
+    job = dict(b=bfloat16 [M, nb], c=float32 [rows, nb] (accumulated into), a=None (own A operand, bfloat16 [M, lda];
+    default: the shared ``a16``, which may be None when every job brings one), a0=0, na=None (columns of the A operand),
+    shift=0, db=None, db2=None, gate_map=None).  c += A[:, a0:a0+na]^T b', b' = b with rows shifted by ``shift`` inside
+    windows of T rows (zeros outside the window)."""
+    ap, M, Na, lda = as2d(a16, torch.bfloat16) if a16 is not None else (None, None, 0, 0)
     arr = (_lib.TnJob * len(jobs))()
     flops = bytes_ = 0.0
+    own_a = set()
     for k, j in enumerate(jobs):
         b, c = j["b"], j["c"]
         bp, Mb, nb, ldb = as2d(b, torch.bfloat16)
         cp, rows, nbc, ldc = as2d(c)
+        ja = j.get("a")
+        if ja is not None:
+            jap, Mj, Naj, jlda = as2d(ja, torch.bfloat16)
+            if ja.data_ptr() not in own_a:
+                own_a.add(ja.data_ptr())
+                bytes_ += 2.0 * Mj * Naj
+        else:
+            assert a16 is not None, "a job without its own A operand needs the shared one"
+            jap, Mj, Naj, jlda = None, M, Na, 0
+        M = Mj if M is None else M
         a0 = j.get("a0", 0)
-        na = j.get("na") or (Na - a0)
+        na = j.get("na") or (Naj - a0)
         gm = j.get("gate_map")
         n_out = na if gm is None else na // 4 * gm[1]
-        assert Mb == M and nbc == nb and rows == n_out, (a16.shape, b.shape, c.shape, a0, na, gm)
+        assert Mb == M and Mj == M and nbc == nb and rows == n_out, (b.shape, c.shape, a0, na, gm)
         for d in (j.get("db"), j.get("db2")):
             assert d is None or (d.is_contiguous() and d.numel() == n_out)
         g6 = (C.c_int32 * 6)(*( (gm[0], gm[1], *gm[2]) if gm is not None else (0, 0, 0, 0, 0, 0)))
-        arr[k] = _lib.TnJob(bp, ldb, nb, j.get("shift", 0), cp, ldc, _ptr(j.get("db")), _ptr(j.get("db2")), a0, na, g6)
+        arr[k] = _lib.TnJob(bp, ldb, nb, j.get("shift", 0), cp, ldc, _ptr(j.get("db")), _ptr(j.get("db2")), a0, na, g6, jap, jlda)
         flops += 2.0 * M * na * nb
         bytes_ += 2.0 * M * nb + 4.0 * n_out * nb
-    bytes_ += 2.0 * M * Na
+    if a16 is not None:
+        bytes_ += 2.0 * M * Na
     _call("tad_mm16_tn", M, T, ap, lda, len(jobs), arr, _stream(), cost=(flops, bytes_))
 
 
