@@ -151,7 +151,7 @@ def test_mm16_tn_accumulates_and_rejects(ops, dev):
     with pytest.raises((RuntimeError, AssertionError)):
         ops.mm16_tn(A, [dict(b=B[:, :4], c=C[:, :4].contiguous())])     # nb not a multiple of 8
     with pytest.raises((RuntimeError, AssertionError, IndexError)):
-        ops.mm16_tn(A, [dict(b=B, c=C)] * 9)                            # more than eight jobs
+        ops.mm16_tn(A, [dict(b=B, c=C)] * 13)                           # more than twelve jobs
 
 
 def test_mm16_tn_jobs_with_their_own_a_operands(ops, dev):
@@ -173,3 +173,22 @@ def test_mm16_tn_jobs_with_their_own_a_operands(ops, dev):
         assert _rel(j["c"], rc) < 2e-5 and _rel(j["db"], rb) < 2e-5
     with pytest.raises((RuntimeError, AssertionError)):
         ops.mm16_tn(None, [dict(b=jobs[0]["b"], c=jobs[0]["c"])])          # no A operand at all
+
+
+def test_mm16_tn_weight_narrower_than_its_padded_operand(ops, dev):
+    """Linear(6 -> 200): the input is stored padded to 8 columns (zeros), the weight gradient is [200, 6]; the product's
+    padding columns must not be written (they would land in the next row of the gradient)."""
+    M = 5000
+    g = torch.Generator(device=dev).manual_seed(5)
+    A = torch.randn(M, 200, device=dev, generator=g).bfloat16()
+    B = torch.zeros(M, 16, device=dev, dtype=torch.bfloat16)
+    B[:, :6] = torch.randn(M, 6, device=dev, generator=g).bfloat16()
+    B[:, 8:14] = 1.0                                                       # neighbouring columns of a wider buffer: not part of b
+    c = torch.full((200, 6), 0.5, device=dev)
+    db = torch.zeros(200, device=dev)
+    ops.mm16_tn(A, [dict(b=B[:, :8], c=c, db=db)])
+    torch.cuda.synchronize()
+    ref = 0.5 + A.double().T @ B[:, :6].double()
+    assert _rel(c, ref) < 2e-5 and _rel(db, A.double().sum(0)) < 2e-5
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.mm16_tn(A, [dict(b=B, c=c)])                                   # 10 columns short: not padding any more

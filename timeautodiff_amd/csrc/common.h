@@ -47,8 +47,20 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __bui
 // column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 __device__ __forceinline__ int acc_row32(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// Sum over the 64 lanes of a wave (all of them active), the same value in every lane.  Four DPP steps inside the
+// rows of 16 lanes (quad swaps, then the half-row and row mirrors: no LDS crossbar round trip as a lane shuffle
+// takes), then the four row sums are read as scalars and added in a fixed order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);     // row_half_mirror
+  v = dpp_add<0x140>(v);     // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }

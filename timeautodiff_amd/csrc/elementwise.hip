@@ -217,16 +217,26 @@ __global__ void layernorm_fwd_kernel(int64_t rows, int D, const float* __restric
     gm[i] = c < D ? gamma[c] : 0.f;
     bt[i] = c < D ? beta[c] : 0.f;
   }
+  // the next row of the wave is fetched before this one is worked on: a row's chain (load, two wave reductions, K more,
+  // stores) is long and the wave has nothing else to overlap it with
+  float xn[NC];
+  auto fetch = [&](int64_t r) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      xn[i] = (r < rows && c < D) ? x[r * ldx + c] : 0.f;
+    }
+  };
+  fetch(wave);
   for (int64_t r = wave; r < rows; r += nwaves) {
-    const float* xr = x + r * ldx;
     float xv[NC];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-      const int c = lane + 64 * i;
-      xv[i] = c < D ? xr[c] : 0.f;
-      if (c < D) s += xv[i];
+      xv[i] = xn[i];
+      s += xv[i];
     }
+    fetch(r + nwaves);
     const float mean = wave_sum(s) / (float)D;
     float v = 0.f;
 #pragma unroll
@@ -359,16 +369,24 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_fc_fwd_kernel(int64_t rows, int D
       wk[k][i] = round16 ? (float)(bf16_t)w : w;
     }
   }
+  float xn[NC];                       // the wave's next row, fetched before the current one is worked on
+  auto fetch = [&](int64_t r) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      xn[i] = (r < rows && c < D) ? x[r * ldx + c] : 0.f;
+    }
+  };
+  fetch(wave);
   for (int64_t r = wave; r < rows; r += nwaves) {
-    const float* xr = x + r * ldx;
     float xv[NC];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-      const int c = lane + 64 * i;
-      xv[i] = c < D ? xr[c] : 0.f;
-      if (c < D) s += xv[i];
+      xv[i] = xn[i];
+      s += xv[i];
     }
+    fetch(r + nwaves);
     const float mean = wave_sum(s) / (float)D;
     float v = 0.f;
 #pragma unroll
@@ -439,10 +457,28 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_fc_bwd_kernel(int64_t rows, int D
   }
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) dbk[k] = 0.f;
+  // operands of the wave's next row, fetched before the current row is worked on (see the forward)
+  float xn[NC], mean_n = 0.f, rstd_n = 0.f, mine_n = 0.f;
+  auto fetch = [&](int64_t r) {
+    const bool live = r < rows;
+    mean_n = live ? mr[2 * r] : 0.f;
+    rstd_n = live ? mr[2 * r + 1] : 0.f;
+    mine_n = (live && lane < K) ? dpred[r * K + lane] : 0.f;       // one coalesced load of the row, broadcast below
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      xn[i] = (live && c < D) ? x[r * ldx + c] : 0.f;
+    }
+  };
+  fetch(wave);
   for (int64_t r = wave; r < rows; r += nwaves) {
-    const float mean = mr[2 * r], rstd = mr[2 * r + 1];
+    const float mean = mean_n, rstd = rstd_n;
     float dp[KMAX], dpq[KMAX];
-    const float mine = lane < K ? dpred[r * K + lane] : 0.f;      // one coalesced load of the row, then broadcasts
+    const float mine = mine_n;
+    float xcur[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) xcur[i] = xn[i];
+    fetch(r + nwaves);
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       dp[k] = __shfl(mine, k, 64);
@@ -456,7 +492,7 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_fc_bwd_kernel(int64_t rows, int D
       const int c = lane + 64 * i;
       xh[i] = 0.f; dxh[i] = 0.f;
       if (c < D) {
-        xh[i] = (x[r * ldx + c] - mean) * rstd;
+        xh[i] = (xcur[i] - mean) * rstd;
         if constexpr (DW) {
           float yv = xh[i] * gm[i] + bt[i];
           if (round16) yv = (float)(bf16_t)yv;

@@ -464,7 +464,7 @@ int launch_nt(NtParams& p, hipStream_t s) {
 // the tile (2 x 4 MFMA blocks) and skips the 32-column blocks of B beyond the operand.  For the recurrent layers
 // (B = x or h_{t-1}, at most 256 wide per tile) a column of the gate gradients is fetched into LDS by one workgroup
 // only.  Stage = 32 reduction rows: A image [32][256] + B image [32][256] bf16 (32 KiB); 4 stages, three in flight.
-constexpr int TN_MAXJOBS = 8;
+constexpr int TN_MAXJOBS = 12;
 constexpr int TN_BK = 32;                      // reduction rows per stage
 constexpr int TN_TA = 256, TN_TB = 256;        // tile: columns of A, columns of B
 constexpr int TN_IMG = TN_BK * 512;            // bytes of one image: [32 rows][256 columns] bf16
@@ -542,6 +542,7 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
   const int ta = tl / J.tiles_b, tb = tl % J.tiles_b;
   const int a_c0 = J.a0 + TN_TA * ta, a_end = J.a0 + J.na;    // first column of the A tile, end of the job's A range
   const int b_c0 = TN_TB * tb, b_end = J.nb;
+  const int c_end = J.nb < (int)J.ldc ? J.nb : (int)J.ldc;     // columns of B beyond a narrower C are padding
   const int wa = wave & 3, wn = wave >> 2;                     // the two waves of a SIMD share their A columns
   int nblk = (b_end - b_c0 + 31) / 32 - 4 * wn;                // 32-column blocks of B this wave multiplies
   nblk = nblk < 0 ? 0 : nblk > 4 ? 4 : nblk;
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int nb = b_c0 + 128 * wn + 32 * j + lr;
-        if (j < nblk && nb < b_end) atomicAdd(J.C + (int64_t)dst * J.ldc + nb, acc[i][j][e]);
+        if (j < nblk && nb < c_end) atomicAdd(J.C + (int64_t)dst * J.ldc + nb, acc[i][j][e]);
       }
       if (want_db && i == wn && lr == 0) {
         atomicAdd(J.db + dst, bacc[e]);
@@ -747,7 +748,7 @@ extern "C" int tad_mm16_tn(int64_t M, int64_t T, const void* A16, int64_t lda, i
     const int64_t jlda = u.A16 ? u.lda : lda;
     TAD_CHECK(ja && al16(ja) && jlda % 8 == 0 && jlda < (1 << 22), "tad_mm16_tn: job %d: no A operand, or rows not 16-byte aligned", k);
     TAD_CHECK(u.a0 >= 0 && u.na >= 8 && u.a0 % 8 == 0 && u.na % 8 == 0 && u.a0 + u.na <= jlda, "tad_mm16_tn: job %d: bad A column range", k);
-    TAD_CHECK(u.ldc >= u.nb && (T > 0 || u.shift == 0) && u.shift > -(T > 0 ? T : 1) && u.shift < (T > 0 ? T : 1), "tad_mm16_tn: job %d: bad ldc / shift", k);
+    TAD_CHECK(u.ldc > u.nb - 8 && u.ldc >= 1 && (T > 0 || u.shift == 0) && u.shift > -(T > 0 ? T : 1) && u.shift < (T > 0 ? T : 1), "tad_mm16_tn: job %d: bad ldc / shift", k);
     TAD_CHECK(u.db || !u.db2, "tad_mm16_tn: job %d: db2 without db", k);
     TnJob& j = p.job[k];
     j.A = reinterpret_cast<const bf16_t*>(ja); j.lda = jlda;

@@ -152,7 +152,7 @@ class FlatParams:
 
     def queue_tn(self, a16, job):
         """Queue one small weight-gradient product (ops.mm16_tn job with its own A operand).  The products of a
-        backward pass that are queued this way leave together at ``flush_tn`` -- one launch per eight jobs, in which
+        backward pass that are queued this way leave together at ``flush_tn`` -- one launch per twelve jobs, in which
         every job gets a share of the chip and a dozen reduction splits instead of a launch of its own with hundreds."""
         j = dict(job)
         j["a"] = a16
@@ -161,8 +161,8 @@ class FlatParams:
     def flush_tn(self):
         """Launch the queued weight-gradient products (deferred to the gradient stream like every weight gradient)."""
         jobs, self._tn_jobs = self._tn_jobs, []
-        for i in range(0, len(jobs), 8):
-            self.defer(ops.mm16_tn, None, jobs[i:i + 8])
+        for i in range(0, len(jobs), ops.TN_MAXJOBS):
+            self.defer(ops.mm16_tn, None, jobs[i:i + ops.TN_MAXJOBS])
 
     def release(self):
         """Issue the queued launches on the side stream; called right before a latency-bound kernel goes to the
@@ -222,6 +222,7 @@ class W16Images:
     def __init__(self, fp):
         self.fp = fp
         self.items = []
+        self.sums = []
         self._ver = -1
 
     @staticmethod
@@ -238,9 +239,28 @@ class W16Images:
             self.items.append((w, ent["tr"], True))
         return ent
 
+    def add_side_by_side(self, ws_, biases):
+        """One forward image [n, sum of the widths, each rounded up to 8] of several weights with the same number of rows,
+        for y = [x_0 | x_1 | ...] [W_0 | W_1 | ...]^T = sum_i x_i W_i^T, and the sum of their biases (float32 [n]),
+        refreshed with the images."""
+        n = ws_[0].shape[0]
+        widths = [-(-w.shape[1] // 8) * 8 for w in ws_]
+        img = self.alloc(n, sum(widths), ws_[0].device)
+        c0 = 0
+        for w, wd in zip(ws_, widths):
+            assert w.shape[0] == n
+            self.items.append((w, img[:n, c0:c0 + wd], False))
+            c0 += wd
+        bsum = torch.zeros(n, dtype=torch.float32, device=ws_[0].device)
+        assert len(biases) == 2
+        self.sums.append((biases[0], biases[1], bsum))
+        return dict(fwd=img, bias=bsum, widths=widths)
+
     def pack(self):
         if self._ver != self.fp.version:
             ops.pack_w16(self.items)
+            for a, b, out in self.sums:
+                torch.add(a, b, out=out)
             self._ver = self.fp.version
 
 
@@ -258,12 +278,14 @@ class Workspace:
         self.bufs = {}
 
     def get(self, name, shape, dtype=torch.float32, zero=False):
+        """zero: True = cleared on every call, "new" = cleared only when (re)allocated (padding nobody writes)."""
         shape = tuple(int(s) for s in shape)
         t = self.bufs.get(name)
-        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+        fresh = t is None or tuple(t.shape) != shape or t.dtype != dtype
+        if fresh:
             t = torch.empty(shape, dtype=dtype, device=self.device)
             self.bufs[name] = t
-        if zero:
+        if zero is True or (zero == "new" and fresh):
             t.zero_()
         return t
 
@@ -385,10 +407,11 @@ class RnnStack:
         else:
             ops.linear_fwd(self.prec, x, w_gl, bias_gl, xproj)
 
-    def forward(self, x, B, T, ws: Workspace, tag, train):
+    def forward(self, x, B, T, ws: Workspace, tag, train, last16=None):
         """x [B*T, in_dim] float32, or bfloat16 where layer 0 takes the bf16-stored-operand products.  Returns the
         float32 output of the last layer; ``self.out16`` holds the bfloat16 copies the sequence kernels wrote beside
-        (per layer, None where a layer wrote none)."""
+        (per layer, None where a layer wrote none).  ``last16``: where the last layer's bfloat16 copy goes instead of a
+        buffer of its own (a [B*T, ndir*H] view, e.g. the leading columns of a wider operand of the next product)."""
         fp, H, nd, prec = self.fp, self.H, self.ndir, self.prec
         BT = B * T
         H4 = 4 * H
@@ -417,6 +440,9 @@ class RnnStack:
             want32 = last or not want16 or (train and not lstm) or (not last and not self.mm16[layer + 1])
             out = ws.get(f"{tag}.out{layer}", (BT, nd * H)) if want32 else None
             out16 = ws.get(f"{tag}.out16_{layer}", (BT, nd * H), dtype=torch.bfloat16) if want16 else None
+            if last and want16 and last16 is not None:
+                assert tuple(last16.shape) == (BT, nd * H) and last16.dtype == torch.bfloat16
+                out16 = last16
             self.out16[layer] = out16
             gates = ws.get(f"{tag}.gates{layer}", (BT, nd * H4), dtype=sdt) if train else None
             cst = ws.get(f"{tag}.c{layer}", (BT, nd * H)) if (train and lstm) else None
@@ -760,7 +786,11 @@ class DenoiserEngine:
                          and all(self.gru.mm16) and all(self.lstm.mm16))
         if self.mm16:
             p_ = self.fp.p
-            self.im = dict(co=self.imgs.add(p_("cond_output.weight"), fwd=True, tr=True),
+            # cond_output and input_proj add up (reference DIFF.py:197-198: x = input_proj(x) + cond_output(cond_out)): one
+            # product over [h_gru | x] with the two weights side by side
+            self.im = dict(co=self.imgs.add(p_("cond_output.weight"), fwd=False, tr=True),
+                           coin=self.imgs.add_side_by_side([p_("cond_output.weight"), p_("input_proj.net.0.weight")],
+                                                           [p_("cond_output.bias"), p_("input_proj.net.0.bias")]),
                            proj=self.imgs.add(p_("proj.net.0.weight"), fwd=True, tr=True),
                            te2=self.imgs.add(p_("time_encode.2.weight"), fwd=True, tr=True))
             if self.time_dim % 8 == 0:
@@ -857,22 +887,24 @@ class DenoiserEngine:
     def _forward16(self, x2, t1, i1, ti2, c2, B, T):
         """The training forward with every tensor that only matrix products read kept as bfloat16: the products
         round their operands to bf16 anyway, so a tensor stored rounded yields the same values as one stored in
-        float32.  What anything else reads stays float32: the input projection (summed with cond_output's result
-        before the one rounding of `proj`'s operand), the GRU's h_t (its backward), the LSTM's last h_t (LayerNorm)."""
+        float32.  What anything else reads stays float32: the GRU's h_t (its backward), the LSTM's last h_t (LayerNorm).
+        input_proj(x) + cond_output(h_gru) is one product over [h_gru | x], summed in the float32 accumulators before the
+        one rounding of `proj`'s operand."""
         fp, ws, prec, H, K, im = self.fp, self.ws, self.prec, self.H, self.K, self.im
         BT = B * T
         b16 = torch.bfloat16
         self.imgs.pack()
-        xh = ws.get("xh", (BT, H))
-        ops.linear_fwd(prec, x2, fp.p("input_proj.net.0.weight"), fp.p("input_proj.net.0.bias"), xh)
+        # [h_gru | x | 0] as one bf16 operand: the GRU writes its part, x is rounded here (as the product would on load)
+        Kp = im["coin"]["widths"][1]
+        gx = ws.get("gx16", (BT, 2 * H + Kp), dtype=b16, zero="new")       # the pad columns stay zero
+        ops.cvt_bf16(x2, gx[:, 2 * H:2 * H + K])
         emb = self.emb.forward(c2, ws, "emb", want16=True)
         fp.join()
         cat = ws.get("cat16", (BT, 4 * H), dtype=b16)
         ta = ws.get("ta16", (BT, H), dtype=b16)
         fp.defer_until_release(self._encodings16, cat, ta, t1, i1, ti2, BT)
-        self.gru.forward(emb, B, T, ws, "gru", True)
-        gout16 = self.gru.out16[self.L - 1]
-        ops.mm16_nt(gout16, im["co"]["fwd"], fp.p("cond_output.bias"), cat[:, :H], residual=xh)
+        self.gru.forward(emb, B, T, ws, "gru", True, last16=gx[:, :2 * H])
+        ops.mm16_nt(gx, im["coin"]["fwd"], im["coin"]["bias"], cat[:, :H])
         fp.join()
         pa = ws.get("pa16", (BT, H), dtype=b16)
         ops.mm16_nt(cat, im["proj"]["fwd"], fp.p("proj.net.0.bias"), pa, act=ACT_RELU)
@@ -969,7 +1001,8 @@ class DenoiserEngine:
         ops.mm16_nt(dpz, img_rows(wt, H, 2 * H), None, denc)
         dtenc = ws.get("dtenc16", (BT, H), dtype=b16)
         ops.mm16_nt(dpz, img_rows(wt, 3 * H, H), None, dtenc)
-        fp.defer(ops.linear_bwd_weight, prec, dxh, x2, fp.g("input_proj.net.0.weight"), db=fp.g("input_proj.net.0.bias"))
+        gx = ws.get("gx16", (BT, 2 * H + im["coin"]["widths"][1]), dtype=b16)
+        fp.queue_tn(dxh, dict(b=gx[:, 2 * H:], c=fp.g("input_proj.net.0.weight"), db=fp.g("input_proj.net.0.bias")))
         fp.defer(ops.colsum, denc[:, :Lh], out_sum=fp.g("t_enc.linear_proj.bias"), row_scale=t1, scale_mul=1.0,
                  out_wsum=fp.g("t_enc.linear_proj.weight"))
         fp.defer(ops.colsum, denc[:, H:H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
@@ -980,7 +1013,11 @@ class DenoiserEngine:
         dta = ws.get("dta16", (BT, H), dtype=b16)
         ops.mm16_nt(dtenc, im["te2"]["tr"], None, dta, relu_of=ta)
         fp.queue_tn(dtenc, dict(b=ta, c=fp.g("time_encode.2.weight"), db=fp.g("time_encode.2.bias")))
-        fp.defer(ops.linear_bwd_weight, prec, dta, ti2, fp.g("time_encode.0.weight"), db=fp.g("time_encode.0.bias"))
+        if "te0" in im:
+            fp.queue_tn(dta, dict(b=ws.get("ti16", (BT, self.time_dim), dtype=b16), c=fp.g("time_encode.0.weight"),
+                                  db=fp.g("time_encode.0.bias")))
+        else:
+            fp.defer(ops.linear_bwd_weight, prec, dta, ti2, fp.g("time_encode.0.weight"), db=fp.g("time_encode.0.bias"))
         dgout = ws.get("dgout", (BT, 2 * H))
         ops.mm16_nt(dxh, im["co"]["tr"], None, dgout)
         fp.queue_tn(dxh, dict(b=gout16, c=fp.g("cond_output.weight"), db=fp.g("cond_output.bias")))

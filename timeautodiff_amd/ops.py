@@ -294,12 +294,16 @@ def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=
                 + (relu_of.element_size() * M * N if relu_of is not None else 0) + (2.0 * M * N if z_out is not None else 0)))
 
 
+TN_MAXJOBS = 12
+
+
 def mm16_tn(a16, jobs, T=0):
-    """Weight gradients from bf16-stored operands, one launch for all ``jobs`` (at most 8):
+    """Weight gradients from bf16-stored operands, one launch for all ``jobs`` (at most ``TN_MAXJOBS`` = 12):
     job = dict(b=bfloat16 [M, nb], c=float32 [rows, nb] (accumulated into), a=None (own A operand, bfloat16 [M, lda];
     default: the shared ``a16``, which may be None when every job brings one), a0=0, na=None (columns of the A operand),
     shift=0, db=None, db2=None, gate_map=None).  c += A[:, a0:a0+na]^T b', b' = b with rows shifted by ``shift`` inside
-    windows of T rows (zeros outside the window)."""
+    windows of T rows (zeros outside the window).  A contiguous c up to 7 columns narrower than b takes the leading
+    columns of the product (b's extra columns are zero padding)."""
     ap, M, Na, lda = as2d(a16, torch.bfloat16) if a16 is not None else (None, None, 0, 0)
     arr = (_lib.TnJob * len(jobs))()
     flops = bytes_ = 0.0
@@ -322,7 +326,7 @@ def mm16_tn(a16, jobs, T=0):
         na = j.get("na") or (Naj - a0)
         gm = j.get("gate_map")
         n_out = na if gm is None else na // 4 * gm[1]
-        assert Mb == M and Mj == M and nbc == nb and rows == n_out, (b.shape, c.shape, a0, na, gm)
+        assert Mb == M and Mj == M and rows == n_out and (nbc == nb or (nb - 8 < nbc < nb and ldc == nbc)), (b.shape, c.shape, a0, na, gm)
         for d in (j.get("db"), j.get("db2")):
             assert d is None or (d.is_contiguous() and d.numel() == n_out)
         g6 = (C.c_int32 * 6)(*( (gm[0], gm[1], *gm[2]) if gm is not None else (0, 0, 0, 0, 0, 0)))
