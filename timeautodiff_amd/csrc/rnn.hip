@@ -93,6 +93,39 @@ __global__ void pack_kernel(PackArgs a) {
 // are read from a copy of theirs in LDS (wl, same order), the rest from global memory through a ring of PF
 // k-blocks in registers; the ring's first loads are issued before the LDS part, which hides their latency.
 // (Routing the LDS blocks through the ring as well was measured slower: the forward LSTM then spills.)
+// The same product with nothing streamed: the first kl k-blocks of W come from their copy in LDS (wl), the last NKR
+// from registers (wres, loaded once before the time loop).  The A tile holds only `arows` rows (the workgroup's real
+// batch rows); the lanes of the other rows of the 32-row MFMA operand supply zeros.  bf16 only.
+template <int NT, int NKR>
+__device__ __forceinline__ void mma_resident(f32x16* acc, const unsigned char* lds_a, int lds_ld, int arows, const uint4* wl, int kl,
+                                             const uint4 (&wres)[NKR][NT], int lane) {
+  const int row = lane & 31, half = lane >> 5;
+  const bool live = row < arows;
+  const unsigned char* abase = lds_a + ((size_t)(live ? row : 0) * lds_ld + 8 * half) * 2;
+  auto afrag = [&](int kk) -> bf16x8 {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(abase + 32 * kk);
+    if (!live) v = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+    return v;
+  };
+  for (int kk = 0; kk < kl; ++kk) {
+    const bf16x8 av = afrag(kk);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const bf16x8 bv = __builtin_bit_cast(bf16x8, wl[(kk * NT + n) * 64 + lane]);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[n], 0, 0, 0);
+    }
+  }
+  bf16x8 av[NKR];
+#pragma unroll
+  for (int p = 0; p < NKR; ++p) av[p] = afrag(kl + p);
+#pragma unroll
+  for (int p = 0; p < NKR; ++p) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[p], __builtin_bit_cast(bf16x8, wres[p][n]), acc[n], 0, 0, 0);
+  }
+}
+
 template <bool BF16, int NT, int PF>
 __device__ __forceinline__ void mma_stream(f32x16* acc, const unsigned char* lds_a, int lds_ld,
                                            const uint4* __restrict__ wp, int nk, int lane, const uint4* wl = nullptr, int kl = 0) {
@@ -195,10 +228,17 @@ struct RnnFwdArgs {
   int B, T, H, NJ, nk, lds_ld, rpw;
   int kl;      // leading k-blocks of every chunk's W_hh image kept in LDS for the whole sequence
   int out16_rows;   // 1: the bf16 copy of h_t is written from the LDS tile in 16-byte pieces (bf16 precision, aligned rows)
+  int tile_rows;    // rows of an h tile in LDS: 32, or rpw in the resident form
 };
 
-template <int CELL, bool BF16, bool ST16, int JPW>
+// NKR > 0, the resident form (small batches: rpw <= 16, one chunk per wave, bf16): nothing of W_hh is streamed inside
+// the time loop -- k-blocks [0, kl) sit in LDS, the last NKR = nk - kl in registers -- and the h tiles hold only the
+// rpw real rows, which is what makes room for kl blocks in LDS.  RL = rpw / 2 (the live accumulator registers) is then
+// a compile-time constant, so that the dead rows cost no registers.  The step of such a launch is a dependent chain
+// (h tile -> product -> gate math -> barrier) in which waiting for W_hh blocks from L2 was the longest link.
+template <int CELL, bool BF16, bool ST16, int JPW, int NKR = 0, int RL = 0>
 __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
+  static_assert(NKR == 0 || (BF16 && JPW == 1 && RL > 0), "resident form: bf16, one chunk per wave, fixed row count");
   constexpr int G = CELL == TAD_CELL_LSTM ? 4 : 3;
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int PF = BF16 ? 4 : 2;
@@ -209,9 +249,9 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int col = lane & 31;
   const int64_t b0 = (int64_t)blockIdx.x * a.rpw;   // rows >= rpw of the 32-row MFMA tile stay empty
-  const size_t buf_bytes = (size_t)32 * a.lds_ld * ESZ;
+  const size_t buf_bytes = (size_t)a.tile_rows * a.lds_ld * ESZ;
   const int H = a.H, T = a.T;
-  const int rlive = a.rpw >> 1;                     // accumulator registers that hold real rows (rpw is 8, 16 or 32)
+  const int rlive = RL > 0 ? RL : (a.rpw >> 1);     // accumulator registers that hold real rows (rpw is 8, 16 or 32)
   const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed);
 
   for (size_t i = threadIdx.x; i < 2 * buf_bytes / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
@@ -220,6 +260,15 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
   uint4* wl = reinterpret_cast<uint4*>(smem + 2 * buf_bytes) + (size_t)wave * a.kl * G * 64;
   if (JPW == 1 && wave < a.NJ) {
     for (int i = 0; i < a.kl * G; ++i) wl[i * 64 + lane] = wp[((int64_t)wave * a.nk * G + i) * 64 + lane];
+  }
+  uint4 wres[NKR > 0 ? NKR : 1][G];
+  if constexpr (NKR > 0) {
+    if (wave < a.NJ) {
+#pragma unroll
+      for (int p = 0; p < NKR; ++p)
+#pragma unroll
+        for (int n = 0; n < G; ++n) wres[p][n] = wp[(((int64_t)wave * a.nk + a.kl + p) * G + n) * 64 + lane];
+    }
   }
 
   float st[JPW][16];   // LSTM: c; GRU: h
@@ -307,7 +356,8 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
 #ifdef EXP_STAMPS
         { RSTAMP(qq); q1 = qq; }
 #endif
-        mma_stream<BF16, G, PF>(acc, cur, a.lds_ld, wp + (int64_t)j * a.nk * G * 64, a.nk, lane, wl, JPW == 1 ? a.kl : 0);
+        if constexpr (NKR > 0) mma_resident<G, NKR>(acc, cur, a.lds_ld, a.tile_rows, wl, a.kl, wres, lane);
+        else mma_stream<BF16, G, PF>(acc, cur, a.lds_ld, wp + (int64_t)j * a.nk * G * 64, a.nk, lane, wl, JPW == 1 ? a.kl : 0);
 #ifdef EXP_STAMPS
         { RSTAMP(qq); q2 = qq; }
 #endif
@@ -655,16 +705,18 @@ int set_lds(K kernel, size_t bytes, size_t (&per_device)[64]) {
   return TAD_OK;
 }
 
-template <int CELL, bool BF16, bool ST16, int JPW>
+template <int CELL, bool BF16, bool ST16, int JPW, int NKR = 0, int RL = 0>
 int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-  auto k = rnn_fwd_kernel<CELL, BF16, ST16, JPW>;
+  auto k = rnn_fwd_kernel<CELL, BF16, ST16, JPW, NKR, RL>;
   static size_t configured[64] = {};
   if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
-  tad_note_kernel("rnn_fwd_kernel<%d, %s, %s, %d>", CELL, BF16 ? "true" : "false", ST16 ? "true" : "false", JPW);
+  tad_note_kernel("rnn_fwd_kernel<%d, %s, %s, %d, %d, %d>", CELL, BF16 ? "true" : "false", ST16 ? "true" : "false", JPW, NKR, RL);
   return TAD_OK;
 }
+
+constexpr int RES_NKR = 8;     // k-blocks of W_hh the resident form keeps in registers (4 VGPRs per k-block and gate)
 
 template <int CELL, bool BF16, bool ST16, int JPW, bool PHASED>
 int launch_bwd(const RnnBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
@@ -740,9 +792,26 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   a.out16_rows = bf && H % 8 == 0 && a.lds_ld % 8 == 0;
   for (int i = 0; i < ndir; ++i)
     if (dirs[i].out16 && (dirs[i].ld_out16 % 8 != 0 || (reinterpret_cast<uintptr_t>(dirs[i].out16) & 15) != 0)) a.out16_rows = 0;
+  a.tile_rows = 32;
   size_t lds = (size_t)2 * 32 * a.lds_ld * (bf ? 2 : 4);
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_fwd: H=%ld needs %zu bytes of LDS in this precision (limit %zu)", (long)H, lds, LDS_LIMIT);
   a.kl = 0;
+  dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
+  hipStream_t s = (hipStream_t)stream;
+  {
+    // small batches: the resident form, if the k-blocks that do not fit its registers fit the LDS beside the h tiles
+    static const char* res_env = getenv("TAD_RNN_RES");      // experiments: 0 = always the streaming form
+    const int kl = g.nkf - RES_NKR;
+    const size_t need = (size_t)2 * a.rpw * a.lds_ld * 2 + (size_t)(kl > 0 ? kl : 0) * g.NJ * G * 1024;
+    if (bf && st16 && g.jpw == 1 && a.rpw <= 16 && kl >= 0 && need <= LDS_LIMIT && !(res_env && atoi(res_env) == 0)) {
+      a.kl = kl; a.tile_rows = a.rpw;
+      if (cell == TAD_CELL_LSTM)
+        return a.rpw == 8 ? launch_fwd<TAD_CELL_LSTM, true, true, 1, RES_NKR, 4>(a, grid, block, need, s)
+                          : launch_fwd<TAD_CELL_LSTM, true, true, 1, RES_NKR, 8>(a, grid, block, need, s);
+      return a.rpw == 8 ? launch_fwd<TAD_CELL_GRU, true, true, 1, RES_NKR, 4>(a, grid, block, need, s)
+                        : launch_fwd<TAD_CELL_GRU, true, true, 1, RES_NKR, 8>(a, grid, block, need, s);
+    }
+  }
   if (g.jpw == 1) {
     static const char* force = getenv("TAD_RNN_KL");      // experiments: k-blocks of W_hh kept in LDS
     const size_t per_kl = (size_t)g.NJ * G * 1024;
@@ -752,8 +821,6 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
     a.kl = (int)kl;
     lds += (size_t)a.kl * per_kl;
   }
-  dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
-  hipStream_t s = (hipStream_t)stream;
 #define TAD_FWD(C, BFV, STV)                                                              \
   (g.jpw == 1 ? launch_fwd<C, BFV, STV, 1>(a, grid, block, lds, s)                         \
               : (g.jpw == 2 ? launch_fwd<C, BFV, STV, 2>(a, grid, block, lds, s) : launch_fwd<C, BFV, STV, 4>(a, grid, block, lds, s)))
