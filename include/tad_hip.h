@@ -140,8 +140,9 @@ int tad_pack_w16(int njobs, const tad_pack_w16_job_t* jobs, tad_stream_t stream)
  * h_{t-1} operand of BPTT.  All jobs of a call share A16 (the gate gradients of a recurrent layer feed dW_ih and both
  * dW_hh), which is then read once from HBM.  db / db2 (or NULL) += the column sums of the job's columns of A16.
  * gate_map = {H, G, slot0..slot3} maps product row blk*4H + 4u + s to row blk*G*H + slot_s*H + u of C_k / db
- * (dropped when slot_s < 0); gate_map[0] == 0: rows as they are.  A16, B16: bf16, 16-byte aligned rows; a0, na, nb
- * multiples of 8.  C_k fp32 (float atomics: sums differ in the last bits from run to run).  At most 12 jobs; the launch's
+ * (dropped when slot_s < 0); gate_map[0] == 0: rows as they are.  A16, B16: bf16, 16-byte aligned rows; a0, nb
+ * multiples of 8; na any (a0 + na rounded up to 8 must stay inside lda: whole 16-byte pieces are read).  C_k fp32
+ * (float atomics: sums differ in the last bits from run to run).  At most 12 jobs; the launch's
  * A16 may be NULL when every job brings its own.  A weight with fewer than a multiple of 8 inputs (Linear(6 -> H))
  * passes B16 padded with zero columns up to nb and ldc_k = its true width, nb_k - 8 < ldc_k < nb_k: the columns of the
  * product beyond ldc_k are not written. */

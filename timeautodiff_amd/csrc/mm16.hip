@@ -476,7 +476,7 @@ struct TnJob {
   const bf16_t* B; int64_t ldb; int nb; int shift;       // B [M, nb]; rows read at m + shift inside windows of T rows
   float* C; int64_t ldc;                                   // C [na', nb] += ..., na' = rows after the gate map
   float* db; float* db2;                                   // += column sums of A (NULL: none)
-  int a0, na;                                              // columns a0 .. a0 + na of A
+  int a0, na, na_out;                                      // columns a0 .. a0 + na of A are multiplied (na a multiple of 8); the first na_out produce rows of C
   int mapH, mapG, slot[4];                                 // gate map of the C rows (mapH == 0: identity)
   int tiles_a, tiles_b, tile_base;
 };
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int na = TN_TA * ta + 64 * wa + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;      // row inside the job's A range
-      if (na >= J.na) continue;
+      if (na >= J.na_out) continue;
       const int dst = tn_map_row(J, na);
       if (dst < 0) continue;
 #pragma unroll
@@ -747,13 +747,14 @@ extern "C" int tad_mm16_tn(int64_t M, int64_t T, const void* A16, int64_t lda, i
     const void* ja = u.A16 ? u.A16 : A16;
     const int64_t jlda = u.A16 ? u.lda : lda;
     TAD_CHECK(ja && al16(ja) && jlda % 8 == 0 && jlda < (1 << 22), "tad_mm16_tn: job %d: no A operand, or rows not 16-byte aligned", k);
-    TAD_CHECK(u.a0 >= 0 && u.na >= 8 && u.a0 % 8 == 0 && u.na % 8 == 0 && u.a0 + u.na <= jlda, "tad_mm16_tn: job %d: bad A column range", k);
+    const int64_t na8 = (u.na + 7) / 8 * 8;               // whole 16-byte pieces are read; columns beyond na produce nothing
+    TAD_CHECK(u.a0 >= 0 && u.na >= 1 && u.a0 % 8 == 0 && u.a0 + na8 <= jlda, "tad_mm16_tn: job %d: bad A column range", k);
     TAD_CHECK(u.ldc > u.nb - 8 && u.ldc >= 1 && (T > 0 || u.shift == 0) && u.shift > -(T > 0 ? T : 1) && u.shift < (T > 0 ? T : 1), "tad_mm16_tn: job %d: bad ldc / shift", k);
     TAD_CHECK(u.db || !u.db2, "tad_mm16_tn: job %d: db2 without db", k);
     TnJob& j = p.job[k];
     j.A = reinterpret_cast<const bf16_t*>(ja); j.lda = jlda;
     j.B = reinterpret_cast<const bf16_t*>(u.B16); j.ldb = u.ldb; j.nb = (int)u.nb; j.shift = (int)u.shift;
-    j.C = u.C; j.ldc = u.ldc; j.db = u.db; j.db2 = u.db2; j.a0 = (int)u.a0; j.na = (int)u.na;
+    j.C = u.C; j.ldc = u.ldc; j.db = u.db; j.db2 = u.db2; j.a0 = (int)u.a0; j.na = (int)na8; j.na_out = (int)u.na;
     j.mapH = 0;
     if (u.gate_map[0] > 0) {
       const int H = u.gate_map[0], G = u.gate_map[1];
@@ -761,7 +762,7 @@ extern "C" int tad_mm16_tn(int64_t M, int64_t T, const void* A16, int64_t lda, i
       for (int sidx = 0; sidx < 4; ++sidx) { TAD_CHECK(u.gate_map[2 + sidx] < G, "tad_mm16_tn: job %d: gate slot beyond G", k); j.slot[sidx] = u.gate_map[2 + sidx]; }
       j.mapH = H; j.mapG = G;
     }
-    j.tiles_a = (int)cdiv64(u.na, TN_TA); j.tiles_b = (int)cdiv64(u.nb, TN_TB); j.tile_base = tiles;
+    j.tiles_a = (int)cdiv64(na8, TN_TA); j.tiles_b = (int)cdiv64(u.nb, TN_TB); j.tile_base = tiles;
     tiles += j.tiles_a * j.tiles_b;
   }
   p.tiles_total = tiles;

@@ -419,6 +419,12 @@ class RnnStack:
         self._in = x
         self._B, self._T = B, T
         self.out16 = [None] * self.L
+        self._in16 = None
+        if train and x.dtype == torch.float32 and self.mm16[0]:
+            # the input-side weight gradient of layer 0 multiplies bf16 operands: a rounded copy of the input (padded to
+            # a multiple of 8 columns with zeros) lets it ride in the layer's one weight-gradient launch
+            self._in16 = ws.get(f"{tag}.in16", (BT, self.in_p(0)), dtype=torch.bfloat16, zero="new")
+            ops.cvt_bf16(x, self._in16[:, :self.in_l(0)])
         inp = x
         for layer in range(self.L):
             sdt = self.store[layer]
@@ -478,6 +484,9 @@ class RnnStack:
                         sl = slice(d * GH, (d + 1) * GH)
                         jobs.append(dict(b=inp[:, d * H:(d + 1) * H], c=fp.g(self.name("weight_ih", layer, d)), a0=d * H4, na=H4,
                                          gate_map=in_map, db=gb_ih[sl], db2=gb_hh[sl] if lstm else None))
+            elif layer == 0 and self._in16 is not None:
+                jobs.append(dict(b=self._in16, c=fp.ggroup(self.name("weight_ih", layer, 0), nd * GH, self.in_l(layer)), a0=0,
+                                 na=nd * H4, gate_map=in_map, db=gb_ih, db2=gb_hh if lstm else None))
             else:
                 self._weight_grads_in(layer, dg, inp, gb_ih, gb_hh, in_map)
             o16 = self.out16[layer]
@@ -1241,6 +1250,14 @@ class VAEEngine:
         self.enc = RnnStack(self.fp, CELL_GRU, self.H, self.F, self.L, enc_dirs, "heads", self.prec)
         self.emb = EmbBlock(self.fp, "Emb.", nb, nc, nn, self.cards, self.E, self.prec)
         self.emb_dec = EmbBlock(self.fp, "Emb_decoder.", nb, nc, nn, self.cards, self.E, self.prec)
+        # bf16 mode: the embedding blocks and the two latent projections' backward take the bf16-stored-operand products
+        self.imgs = W16Images(self.fp)
+        self.emb.use_mm16(self.imgs)
+        self.emb_dec.use_mm16(self.imgs)
+        self.im = {}
+        if MM16 and self.prec == BF16 and self.H % 8 == 0 and all(self.enc.mm16):
+            self.im = dict(fc_mu=self.imgs.add(self.fp.p("fc_mu.weight"), fwd=False, tr=True),
+                           fc_logvar=self.imgs.add(self.fp.p("fc_logvar.weight"), fwd=False, tr=True))
         self.ws = Workspace(device)
 
     def encoder(self, inp, eps, train=False, tag="enc", kld_sum=None):
@@ -1350,8 +1367,23 @@ class VAEEngine:
         dlv = ws.get("dlv", (BT, Lt))
         ops.vae_reparam_bwd(dz, mu, lv, eps2, beta / (global_rows * Lt), dmu, dlv)
         dhh = ws.get("dhh", (BT, 2 * H))
-        _lin_bwd(fp, prec, dmu, hh[:, :H], fp.p("fc_mu.weight"), fp.g("fc_mu.weight"), fp.g("fc_mu.bias"), dx=dhh[:, :H])
-        _lin_bwd(fp, prec, dlv, hh[:, H:], fp.p("fc_logvar.weight"), fp.g("fc_logvar.weight"), fp.g("fc_logvar.bias"), dx=dhh[:, H:])
+        o16 = self.enc.out16[self.L - 1] if self.im else None
+        if o16 is not None:
+            # Linear(H -> lat): a weight gradient of lat rows over all B*T samples and an input gradient of reduction
+            # length lat; as bf16-stored products they read [dmu | dlogvar] (rounded, each padded to 8 columns) and the
+            # bf16 copy of the encoder's output
+            Lp = -(-Lt // 8) * 8
+            self.imgs.pack()
+            d16 = ws.get("dml16", (BT, 2 * Lp), dtype=torch.bfloat16, zero="new")
+            ops.cvt_bf16(dmu, d16[:, :Lt])
+            ops.cvt_bf16(dlv, d16[:, Lp:Lp + Lt])
+            fp.queue_tn(d16, dict(b=o16[:, :H], c=fp.g("fc_mu.weight"), db=fp.g("fc_mu.bias"), a0=0, na=Lt))
+            fp.queue_tn(d16, dict(b=o16[:, H:], c=fp.g("fc_logvar.weight"), db=fp.g("fc_logvar.bias"), a0=Lp, na=Lt))
+            ops.mm16_nt(d16[:, :Lp], self.im["fc_mu"]["tr"], None, dhh[:, :H])
+            ops.mm16_nt(d16[:, Lp:], self.im["fc_logvar"]["tr"], None, dhh[:, H:])
+        else:
+            _lin_bwd(fp, prec, dmu, hh[:, :H], fp.p("fc_mu.weight"), fp.g("fc_mu.weight"), fp.g("fc_mu.bias"), dx=dhh[:, :H])
+            _lin_bwd(fp, prec, dlv, hh[:, H:], fp.p("fc_logvar.weight"), fp.g("fc_logvar.weight"), fp.g("fc_logvar.bias"), dx=dhh[:, H:])
         de = self.enc.backward(dhh, ws, "enc", need_dx=True)
         self.emb.backward(de, ws, "emb")
         fp.join()
