@@ -115,14 +115,20 @@ __device__ __forceinline__ void mma_resident(f32x16* acc, const unsigned char* l
       acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[n], 0, 0, 0);
     }
   }
-  bf16x8 av[NKR];
+  // A fragments four k-blocks at a time: their LDS latency is paid once per group, at 16 registers
 #pragma unroll
-  for (int p = 0; p < NKR; ++p) av[p] = afrag(kl + p);
+  for (int p0 = 0; p0 < NKR; p0 += 4) {
+    bf16x8 av[4];
 #pragma unroll
-  for (int p = 0; p < NKR; ++p) {
+    for (int p = 0; p < 4; ++p)
+      if (p0 + p < NKR) av[p] = afrag(kl + p0 + p);
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[p], __builtin_bit_cast(bf16x8, wres[p][n]), acc[n], 0, 0, 0);
+    for (int p = 0; p < 4; ++p)
+      if (p0 + p < NKR) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[p], __builtin_bit_cast(bf16x8, wres[p0 + p][n]), acc[n], 0, 0, 0);
+      }
   }
 }
 
@@ -801,13 +807,18 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   {
     // small batches: the resident form, if the k-blocks that do not fit its registers fit the LDS beside the h tiles
     static const char* res_env = getenv("TAD_RNN_RES");      // experiments: 0 = always the streaming form
-    const int kl = g.nkf - RES_NKR;
+    // (the full-tile GRU keeps one k-block fewer in registers: its 16 live accumulator rows need them)
+    const int nkr = (cell == TAD_CELL_GRU && a.rpw == 32) ? RES_NKR - 1 : RES_NKR;
+    const int kl = g.nkf - nkr;
     const size_t need = (size_t)2 * a.rpw * a.lds_ld * 2 + (size_t)(kl > 0 ? kl : 0) * g.NJ * G * 1024;
-    if (bf && st16 && g.jpw == 1 && a.rpw <= 16 && kl >= 0 && need <= LDS_LIMIT && !(res_env && atoi(res_env) == 0)) {
+    // (full 32-row tiles: the GRU's three gates leave room in LDS and registers at H = 200, the LSTM's four do not)
+    const bool rows_ok = a.rpw <= 16 || cell == TAD_CELL_GRU;
+    if (bf && st16 && g.jpw == 1 && rows_ok && kl >= 0 && need <= LDS_LIMIT && !(res_env && atoi(res_env) == 0)) {
       a.kl = kl; a.tile_rows = a.rpw;
       if (cell == TAD_CELL_LSTM)
         return a.rpw == 8 ? launch_fwd<TAD_CELL_LSTM, true, true, 1, RES_NKR, 4>(a, grid, block, need, s)
                           : launch_fwd<TAD_CELL_LSTM, true, true, 1, RES_NKR, 8>(a, grid, block, need, s);
+      if (a.rpw == 32) return launch_fwd<TAD_CELL_GRU, true, true, 1, RES_NKR - 1, 16>(a, grid, block, need, s);
       return a.rpw == 8 ? launch_fwd<TAD_CELL_GRU, true, true, 1, RES_NKR, 4>(a, grid, block, need, s)
                         : launch_fwd<TAD_CELL_GRU, true, true, 1, RES_NKR, 8>(a, grid, block, need, s);
     }
