@@ -160,7 +160,7 @@ def main_tn():
     H = 8
     lstm_in, lstm_hid = (H, 4, (0, 1, 2, 3)), (H, 4, (0, 1, 2, 3))
     gru_in, gru_hid = (H, 3, (0, 1, 2, -1)), (H, 3, (0, 1, -1, 2))
-    for (m, T) in [(24, 8), (72 * 3, 24), (1000, 0), (4096, 8)]:
+    for (m, T) in ([] if os.environ.get("TAD_MM16_DBG", "0") != "0" else [(24, 8), (72 * 3, 24), (1000, 0), (4096, 8)]):
         tn_case(m, 64, [(0, 64, 40, 0, None, True)], T=T)
         tn_case(m, 64, [(0, 64, 16, 0, lstm_in, True), (0, 32, 8, -1, lstm_hid, False), (32, 32, 8, 1, lstm_hid, False)], T=T or 8) if (T and m % T == 0) else None
         tn_case(m, 64, [(0, 64, 24, 0, gru_in, True), (0, 32, 8, -1, gru_hid, True), (32, 32, 8, 1, gru_hid, True)], T=T or 8) if (T and m % T == 0) else None

@@ -55,15 +55,19 @@ def main():
         lib = _lib.load()
         if hasattr(lib, "tad_dbg_rnn_stamps"):          # diagnostic build (-DEXP_STAMPS) only
             import ctypes
-            for nm, dirs_ in (("train", fd), ("infer", fi)):
+            for nm, dirs_ in (("train", fd), ("infer", fi), ("bwd", bd)):
                 buf = (ctypes.c_ulonglong * 8)()
                 lib.tad_dbg_rnn_stamps(None, 1)
-                ops.rnn_fwd(cell, prec, B, T, H, dirs_)
+                if nm == "bwd":
+                    ops.rnn_bwd(cell, prec, B, T, H, dirs_)
+                else:
+                    ops.rnn_fwd(cell, prec, B, T, H, dirs_)
                 torch.cuda.synchronize()
                 lib.tad_dbg_rnn_stamps(buf, 0)
                 n = max(buf[7], 1)
-                names = ["seed", "mma", "xproj prefetch issue", "gate math + stores", "barrier"]
-                print(f"  fwd({nm}) cycles per step (wave 0): " + ", ".join(f"{k} {buf[i] / n:.0f}" for i, k in enumerate(names)))
+                names = (["operand fetch (drained)", "gate math + stores", "barrier 1", "mma", "barrier 2"] if nm == "bwd"
+                         else ["seed", "mma", "xproj prefetch issue", "gate math + stores", "barrier"])
+                print(f"  {nm} cycles per step (wave 0): " + ", ".join(f"{k} {buf[i] / n:.0f}" for i, k in enumerate(names)))
 
 
 if __name__ == "__main__":

@@ -191,6 +191,53 @@ __device__ __forceinline__ void mma_stream(f32x16* acc, const unsigned char* lds
   }
 }
 
+// One chunk's product of the backward pass (bf16, one accumulator) with most of the transposed W_hh image resident:
+// k-blocks [0, kl) come from the wave's copy in LDS (wl), the next NKR from registers (wres, loaded once before the
+// time loop), only the rest is streamed from L2 through the ring, whose first loads are issued before everything else.
+template <int PF, int NKR>
+__device__ __forceinline__ void mma_mixed(f32x16& acc, const unsigned char* lds_a, int lds_ld, const uint4* __restrict__ wp, int nk, int lane,
+                                          const uint4* wl, int kl, const uint4 (&wres)[NKR > 0 ? NKR : 1]) {
+  const int row = lane & 31, half = lane >> 5;
+  const unsigned char* ab = lds_a + ((size_t)row * lds_ld + 8 * half) * 2;
+  auto afrag = [&](int kk) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(ab + 32 * kk); };
+  const int ks0 = kl + NKR;
+  uint4 ring[PF];
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (ks0 + p < nk) ring[p] = wp[(int64_t)(ks0 + p) * 64 + lane];
+#pragma unroll 4
+  for (int kk = 0; kk < kl; ++kk) {
+    const bf16x8 av = afrag(kk);
+    const bf16x8 bv = __builtin_bit_cast(bf16x8, wl[kk * 64 + lane]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+  }
+  if constexpr (NKR > 0) {
+#pragma unroll
+    for (int p0 = 0; p0 < NKR; p0 += 4) {
+      bf16x8 av[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (p0 + p < NKR) av[p] = afrag(kl + p0 + p);
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (p0 + p < NKR) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[p], __builtin_bit_cast(bf16x8, wres[p0 + p]), acc, 0, 0, 0);
+    }
+  }
+  for (int kk0 = ks0; kk0 < nk; kk0 += PF) {
+    bf16x8 av[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) av[p] = afrag(kk0 + p < nk ? kk0 + p : nk - 1);
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int kk = kk0 + p;
+      if (kk < nk) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[p], __builtin_bit_cast(bf16x8, ring[p]), acc, 0, 0, 0);
+        if (kk + PF < nk) ring[p] = wp[(int64_t)(kk + PF) * 64 + lane];
+      }
+    }
+  }
+}
+
 template <bool BF16>
 __device__ __forceinline__ void lds_put(unsigned char* base, int lds_ld, int row, int col, float v) {
   if constexpr (BF16) reinterpret_cast<bf16_t*>(base)[(size_t)row * lds_ld + col] = (bf16_t)v;
@@ -453,10 +500,15 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
 struct RnnBwdArgs {
   tad_rnn_bwd_dir_t d[MAXDIR];
   int B, T, H, NJ, width, lds_ld, nk_total, nk_gate, rpw;
+  int kl;      // leading k-blocks of every chunk's transposed W_hh image kept in LDS for the whole sequence (one-pass bf16 form)
 };
 
-template <int CELL, bool BF16, bool ST16, int JPW, bool PHASED>
+// NKR: k-blocks [kl, kl + NKR) of the wave's image stay in registers for the whole sequence (one-pass bf16 form with one
+// chunk per wave).  Streaming all 52 (LSTM, H = 200) from L2 on every step was what bounded the step: the vector L1 of a
+// CU fills at 10-20 bytes per clock, and 364 KB per workgroup and step went through it.
+template <int CELL, bool BF16, bool ST16, int JPW, bool PHASED, int NKR = 0>
 __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
+  static_assert(NKR == 0 || (BF16 && JPW == 1 && !PHASED), "register-resident k-blocks: one-pass bf16 form, one chunk per wave");
   constexpr int G = CELL == TAD_CELL_LSTM ? 4 : 3;
   constexpr int PF = BF16 ? 4 : 2;
   typedef Slots<ST16> SL;
@@ -476,6 +528,23 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
     const size_t words = (size_t)32 * a.lds_ld * (BF16 ? 2 : 4) / 4;
     for (size_t i = threadIdx.x; i < words; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
     __syncthreads();
+  }
+
+  constexpr bool MIXED = BF16 && JPW == 1 && !PHASED;
+  const uint4* wl = nullptr;
+  uint4 wres[NKR > 0 ? NKR : 1];
+  if constexpr (MIXED) {
+    // the wave's own part of the LDS behind the gate-gradient tile: written and read by this wave only
+    uint4* w = reinterpret_cast<uint4*>(smem + (size_t)32 * a.lds_ld * 2) + (size_t)wave * a.kl * 64;
+    if (wave < a.NJ) {
+      const uint4* src = wp + (int64_t)wave * a.nk_total * 64;
+      for (int i = 0; i < a.kl; ++i) w[i * 64 + lane] = src[i * 64 + lane];
+      if constexpr (NKR > 0) {
+#pragma unroll
+        for (int q = 0; q < NKR; ++q) wres[q] = src[(a.kl + q) * 64 + lane];
+      }
+    }
+    wl = w;
   }
 
   f32x16 acc[JPW];
@@ -527,9 +596,16 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
     if (wave < a.NJ) fetch(0, 0, false);
   }
 
+#ifdef EXP_STAMPS
+  unsigned long long sFetch = 0, sGate = 0, sBar1 = 0, sMma = 0, sBar2 = 0;
+#endif
   for (int step = 0; step < T; ++step) {
     const int n = T - 1 - step;                       // forward step being undone
     const int tt = d.reverse ? T - 1 - n : n;
+    RSTAMP(s0);
+#ifdef EXP_STAMPS
+    unsigned long long s1 = s0;
+#endif
     // ---- phase 1: gate gradients for the owned (row, unit) elements
 #pragma unroll
     for (int jj = 0; jj < JPW; ++jj) {
@@ -538,6 +614,9 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
         const int u = 32 * j + col;
         const bool uok = u < H;
         if constexpr (!PREFETCH) fetch(step, jj, false);
+#ifdef EXP_STAMPS
+        { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RSTAMP(qq); s1 = qq; }
+#endif
         const uint32_t goff = (uint32_t)(((4 * half * T + tt) * (int)d.ld_dgates + 4 * u) * SL::ESZ);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -592,18 +671,28 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
         }
       }
     }
+    RSTAMP(s2);
     if constexpr (PREFETCH) {
       if (wave < a.NJ && step + 1 < T) fetch(step + 1, 0, true);
     }
     // ---- phase 2: dh_rec = dgates * W_hh (K = G * width), A operand from LDS
     if constexpr (!PHASED) {
       __syncthreads();
+      RSTAMP(s3);
 #pragma unroll
       for (int jj = 0; jj < JPW; ++jj) {
         const int j = wave + jj * nw;
-        if (j < a.NJ) mma_stream<BF16, 1, PF>(&acc[jj], smem, a.lds_ld, wp + (int64_t)j * a.nk_total * 64, a.nk_total, lane);
+        if (j < a.NJ) {
+          if constexpr (MIXED) mma_mixed<PF, NKR>(acc[jj], smem, a.lds_ld, wp + (int64_t)j * a.nk_total * 64, a.nk_total, lane, wl, a.kl, wres);
+          else mma_stream<BF16, 1, PF>(&acc[jj], smem, a.lds_ld, wp + (int64_t)j * a.nk_total * 64, a.nk_total, lane);
+        }
       }
+      RSTAMP(s4);
       __syncthreads();
+      RSTAMP(s5);
+#ifdef EXP_STAMPS
+      sFetch += s1 - s0; sGate += s2 - s1; sBar1 += s3 - s2; sMma += s4 - s3; sBar2 += s5 - s4;
+#endif
     } else {
       // the tile does not fit LDS: one gate at a time, re-read from the dgates rows this thread wrote itself
       for (int g = 0; g < G; ++g) {
@@ -635,6 +724,12 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
       }
     }
   }
+#ifdef EXP_STAMPS
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_rnn_stamps[0], sFetch); atomicAdd(&g_rnn_stamps[1], sGate); atomicAdd(&g_rnn_stamps[2], sBar1);
+    atomicAdd(&g_rnn_stamps[3], sMma); atomicAdd(&g_rnn_stamps[4], sBar2); atomicAdd(&g_rnn_stamps[7], (unsigned long long)T);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -724,15 +819,17 @@ int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream
 
 constexpr int RES_NKR = 8;     // k-blocks of W_hh the resident form keeps in registers (4 VGPRs per k-block and gate)
 
-template <int CELL, bool BF16, bool ST16, int JPW, bool PHASED>
+constexpr int BWD_NKR = 16;    // k-blocks of the transposed W_hh image the backward keeps in registers (4 VGPRs each)
+
+template <int CELL, bool BF16, bool ST16, int JPW, bool PHASED, int NKR = 0>
 int launch_bwd(const RnnBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-  auto k = rnn_bwd_kernel<CELL, BF16, ST16, JPW, PHASED>;
+  auto k = rnn_bwd_kernel<CELL, BF16, ST16, JPW, PHASED, NKR>;
   static size_t configured[64] = {};
   if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
-  tad_note_kernel("rnn_bwd_kernel<%d, %s, %s, %d, %s>", CELL, BF16 ? "true" : "false", ST16 ? "true" : "false", JPW,
-                  PHASED ? "true" : "false");
+  tad_note_kernel("rnn_bwd_kernel<%d, %s, %s, %d, %s, %d>", CELL, BF16 ? "true" : "false", ST16 ? "true" : "false", JPW,
+                  PHASED ? "true" : "false", NKR);
   return TAD_OK;
 }
 
@@ -795,6 +892,16 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   a.B = (int)B; a.T = (int)T; a.H = (int)H; a.NJ = g.NJ; a.nk = g.nkf;
   a.rpw = rows_per_wg(B, ndir);
   a.lds_ld = g.width + (bf ? 8 : 4);
+  {
+    // The training LSTM at full 32-row tiles streams 36 of its 52 W_hh blocks per wave and step; two rounds of
+    // 16-row workgroups in the resident form (nothing streamed) are faster when that form fits (at H = 200: 330 -> 305 us
+    // for 4096 windows).  Without the gate stash (inference) the streaming form at 32 rows wins.
+    static const char* force = getenv("TAD_RNN_RPW");
+    const int kl = g.nkf - RES_NKR;
+    const size_t need16 = (size_t)2 * 16 * a.lds_ld * 2 + (size_t)(kl > 0 ? kl : 0) * g.NJ * G * 1024;
+    if (!force && cell == TAD_CELL_LSTM && a.rpw == 32 && bf && st16 && g.jpw == 1 && kl >= 0 && need16 <= LDS_LIMIT && dirs[0].gates)
+      a.rpw = 16;
+  }
   a.out16_rows = bf && H % 8 == 0 && a.lds_ld % 8 == 0;
   for (int i = 0; i < ndir; ++i)
     if (dirs[i].out16 && (dirs[i].ld_out16 % 8 != 0 || (reinterpret_cast<uintptr_t>(dirs[i].out16) & 15) != 0)) a.out16_rows = 0;
@@ -878,6 +985,24 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, 
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_bwd: H=%ld needs %zu bytes of LDS (limit %zu)", (long)H, lds, LDS_LIMIT);
   dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
+  a.kl = 0;
+  if (bf && g.jpw == 1 && !phased) {
+    // one-pass bf16 form, one chunk per wave: the transposed W_hh image stays on the chip as far as it fits -- the
+    // leading k-blocks of every wave in the LDS behind the tile, the next BWD_NKR in registers when that many are left
+    static const char* kl_env = getenv("TAD_RNN_BWD_KL");      // experiments: cap on the k-blocks kept in LDS (0 with
+    static const char* nkr_env = getenv("TAD_RNN_BWD_NKR");    // TAD_RNN_BWD_NKR=0: the streaming form)
+    int64_t kl = (int64_t)((LDS_LIMIT - lds) / ((size_t)g.NJ * 1024));
+    if (kl > g.nkb) kl = g.nkb;
+    if (kl_env && atoi(kl_env) < kl) kl = atoi(kl_env);
+    // (with an fp32 gate stash the one-pass form has no registers to spare)
+    const bool regs = st16 && g.nkb - kl >= BWD_NKR && !(nkr_env && atoi(nkr_env) == 0);
+    a.kl = (int)kl;
+    lds += (size_t)kl * g.NJ * 1024;
+    if (regs) {
+      if (cell == TAD_CELL_LSTM) return launch_bwd<TAD_CELL_LSTM, true, true, 1, false, BWD_NKR>(a, grid, block, lds, s);
+      return launch_bwd<TAD_CELL_GRU, true, true, 1, false, BWD_NKR>(a, grid, block, lds, s);
+    }
+  }
 #define TAD_BWD2(C, BFV, STV, J) (phased ? launch_bwd<C, BFV, STV, J, true>(a, grid, block, lds, s) : launch_bwd<C, BFV, STV, J, false>(a, grid, block, lds, s))
 #define TAD_BWD(C, BFV, STV) (g.jpw == 1 ? TAD_BWD2(C, BFV, STV, 1) : (g.jpw == 2 ? TAD_BWD2(C, BFV, STV, 2) : TAD_BWD2(C, BFV, STV, 4)))
   if (cell == TAD_CELL_LSTM) return bf ? (st16 ? TAD_BWD(TAD_CELL_LSTM, true, true) : TAD_BWD(TAD_CELL_LSTM, true, false)) : TAD_BWD(TAD_CELL_LSTM, false, false);
