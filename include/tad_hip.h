@@ -340,6 +340,29 @@ int tad_layernorm_bwd(int64_t rows, int D, const float* dy, int64_t lddy, const 
 int tad_gather_rows(int64_t rows, int64_t row_len, const float* src, const int64_t* idx, float* out,
                     tad_stream_t stream);
 
+/* The random draws of one training iteration on the device (DIFF.py:306 `random.sample(all_indices, batch_size)`,
+ * DIFF.py:317 `torch.rand(B, T, 1).sort(1)[0]`, DIFF.py:253 `torch.randint(0, diffusion_steps, size=(B,))`,
+ * DIFF.py:108 `torch.randn_like(x)`), for the trainers' `draws="device"` mode: idx[B] = B distinct window indices in
+ * [0, N) (a keyed bijection of [0, N) applied to 0..B-1), t[B, T] = T uniforms in [0, 1) per sample in ascending
+ * order, i_idx[B] uniform in [0, n_steps), noise[B, T, K] standard normals.  Counter-based (Philox4x32-10 keyed by
+ * `seed`, iteration `counter` < 2^32): the same (seed, counter) gives the same batch on every rank and in every
+ * replay; nothing is kept between calls.  Any of the four outputs may be NULL.  The values are NOT the reference's
+ * (its CPU generators cannot be replayed on the device); `draws="reference"` keeps those. */
+int tad_draw_batch(uint64_t seed, uint64_t counter, int64_t N, int64_t B, int64_t T, int64_t K, int n_steps,
+                   int64_t* idx, float* t, int32_t* i_idx, float* noise, tad_stream_t stream);
+
+/* `optimizer.zero_grad()` over the flat gradient buffer (DIFF.py:321, VAE.py:343) and the other clears of a step
+ * (an unused column block of the concatenated encodings, DIFF.py:200-203 with the step encoding left out): zero
+ * `rows` rows of `row_bytes` bytes, `ld_bytes` apart (4-byte granularity). */
+int tad_zero_2d(int64_t rows, int64_t row_bytes, void* p, int64_t ld_bytes, tad_stream_t stream);
+/* dst[r, :cols] = src[r, :cols] (float32): the copy of a layer input into its zero-padded buffer (VAE.py:147-151:
+ * the encoders read x with F columns; the bf16 kernels want a multiple of 8). */
+int tad_copy_2d(int64_t rows, int64_t cols, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
+                tad_stream_t stream);
+/* out = a + b (float32 vectors): the bias of `input_proj(x) + cond_output(h)` computed as one product
+ * (DIFF.py:197-198). */
+int tad_add_vec(int64_t n, const float* a, const float* b, float* out, tad_stream_t stream);
+
 /* Minibatch of sliding windows straight from the [rows, F] table they are cut from
  * (dataprovider_pypots.py:75-87 `sliding_window` followed by the trainers' index gather, DIFF.py:320,
  * VAE.py:340-348): out[b, t, :] = table[idx[b] * stride + t, :], b < B, t < T.  The caller guarantees

@@ -881,3 +881,56 @@ def test_ln_fc_fused_equals_the_separate_launches(ops, dev, prec, rows, D, K):
     assert torch.equal(mr, mr2) and torch.equal(y, y2)
     assert rel(pred2, pred) < tol and rel(dx2, dx) < tol
     assert rel(dW2 - 1, dW) < tol and rel(db2 - 1, db) < 1e-5 and rel(dga2 - 1, dga) < tol and rel(dbe2 - 1, dbe) < tol
+
+
+@pytest.mark.parametrize("N,B,T,K", [(1000, 64, 24, 6), (64, 64, 24, 6), (5, 3, 7, 1), (1, 1, 1, 1), (70001, 4096, 24, 6), (300, 100, 96, 3),
+                                       (2000, 33, 200, 5)])
+def test_draw_batch_vs_oracle(ops, dev, N, B, T, K):
+    """tad_draw_batch against its numpy restatement: window indices, diffusion steps and the sorted uniforms bit-exact,
+    normals to 2e-6 absolute (log / sin / cos of the device library against numpy's); a second call with the same (seed,
+    counter) repeats the batch, another counter gives another."""
+    from oracle import draws
+    seed, counter = 0x1234567890ABCDEF, 41
+    idx = torch.empty(B, dtype=torch.int64, device=dev)
+    t = torch.empty(B, T, 1, device=dev)
+    i = torch.empty(B, dtype=torch.int32, device=dev)
+    noise = torch.empty(B, T, K, device=dev)
+    ops.draw_batch(seed, counter, N, B, T, K, 100, idx=idx, t=t, i=i, noise=noise)
+    ref = draws.draw_batch(seed, counter, N, B, T, K, 100)
+    assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+    assert np.array_equal(i.cpu().numpy(), ref["i"])
+    assert np.array_equal(t.cpu().numpy()[:, :, 0], ref["t"])
+    assert np.abs(noise.cpu().numpy() - ref["noise"]).max() < 2e-6 * max(1.0, np.abs(ref["noise"]).max())
+    idx2, n2 = torch.empty_like(idx), torch.empty_like(noise)
+    ops.draw_batch(seed, counter, N, B, T, K, 100, idx=idx2, noise=n2)           # outputs left out are not drawn
+    assert torch.equal(idx, idx2) and torch.equal(noise, n2)
+    ops.draw_batch(seed, counter + 1, N, B, T, K, 100, idx=idx2, noise=n2)
+    assert not torch.equal(noise, n2)
+    with pytest.raises(Exception):
+        ops.draw_batch(seed, counter, B - 1, B, T, K, 100, idx=idx)             # fewer windows than the sample
+
+
+def test_zero_copy_add_helpers(ops, dev):
+    """The fills / copies of a step (zero_grad, pad columns, the bias of a fused product) against torch."""
+    for n in (1, 3, 4, 5, 1027, 3476297):
+        g = torch.randn(n + 8, device=dev)
+        ops.zero_(g[4:4 + n])                            # 16-byte aligned start
+        assert float(g[4:4 + n].abs().sum()) == 0 and float(g[:4].abs().min()) > 0 and float(g[4 + n:].abs().min()) > 0
+        g = torch.randn(n + 8, device=dev)
+        ops.zero_(g[1:1 + n])                            # unaligned start
+        assert float(g[1:1 + n].abs().sum()) == 0 and float(g[:1].abs().min()) > 0 and float(g[1 + n:].abs().min()) > 0
+    m = torch.randn(37, 40, device=dev)
+    keep = m.clone()
+    ops.zero_(m[:, 8:20])
+    keep[:, 8:20] = 0
+    assert torch.equal(m, keep)
+    mb = torch.randn(9, 16, device=dev).bfloat16()
+    ops.zero_(mb[:, 4:8])
+    assert float(mb[:, 4:8].float().abs().sum()) == 0 and float(mb[:, :4].float().abs().min()) > 0
+    src = torch.randn(50, 28, device=dev)
+    dst = torch.full((50, 32), 7.0, device=dev)
+    ops.copy_2d(src, dst[:, :28])
+    assert torch.equal(dst[:, :28], src) and float((dst[:, 28:] - 7).abs().sum()) == 0
+    a, b, out = torch.randn(401, device=dev), torch.randn(401, device=dev), torch.empty(401, device=dev)
+    ops.add_vec(a, b, out)
+    assert torch.equal(out, a + b)

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tad_abi_version() == 7
+    assert lib.tad_abi_version() == 8
     assert lib.tad_rnn_packed_bytes(1, 200, 4) == 7 * (4 * 224 // 16) * 1024
     assert lib.tad_rnn_packed_bytes(0, 200, 3) == 7 * (3 * 224 // 8) * 1024
     assert lib.tad_rnn_packed_bytes(0, 0, 4) == -1

@@ -316,3 +316,28 @@ def test_posthoc_predictor_matches_reference():
         opt.step({k: v.reshape(sd[k].shape) for k, v in g_.items()})
         curve.append(l_)
     assert np.max(np.abs(np.array(curve) - z["curve"]) / z["curve"]) < 1e-4
+
+
+def test_philox_known_answers_and_draw_properties():
+    """The counter-based generator behind the trainers' draws="device" mode: Philox4x32-10 against the known-answer
+    vectors of the Random123 distribution (kat_vectors: zeros, all ones, digits of pi), then the properties of a drawn
+    batch the reference's draws have (DIFF.py:306, 317, 253, 108): distinct in-range indices, ascending time points
+    in [0, 1), steps in range, unit normals; and the same (seed, counter) gives the same batch."""
+    from oracle import draws
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = draws.philox4x32_10(*[np.uint32(c) for c in ctr], *key)
+        assert tuple(int(g) for g in got) == want
+    for N, B in [(1000, 64), (64, 64), (5, 3), (1, 1), (70001, 4096)]:
+        d = draws.draw_batch(99, 7, N, B, 24, 6, 100)
+        assert len(set(d["idx"].tolist())) == B and d["idx"].min() >= 0 and d["idx"].max() < N
+        assert (np.diff(d["t"], axis=1) >= 0).all() and d["t"].min() >= 0 and d["t"].max() < 1
+        assert d["i"].min() >= 0 and d["i"].max() < 100
+    d2 = draws.draw_batch(99, 7, 70001, 4096, 24, 6, 100)
+    assert all(np.array_equal(d[k], d2[k]) for k in d)
+    assert abs(float(d["noise"].mean())) < 5e-3 and abs(float(d["noise"].std()) - 1) < 5e-3
+    assert abs(float(d["t"].mean()) - 0.5) < 5e-3
+    d3 = draws.draw_batch(99, 8, 70001, 4096, 24, 6, 100)
+    assert not np.array_equal(d["idx"], d3["idx"]) and not np.array_equal(d["noise"], d3["noise"])

@@ -247,13 +247,12 @@ class DiffusionTrainer:
         # the loss partial sum lives right behind the gradients in the flat buffer: the last all-reduce of a step
         # carries it along
         self.loss_sum = self.eng.fp.slots(1)
-        self.gen = None
         if draws == "device":
-            self.gen = torch.Generator(device=d)
-            self.gen.manual_seed(torch.initial_seed())
+            # counter-based draws on the device: seeded like torch's generators (torch.manual_seed decides the run)
+            self._draw_seed, self._draw_count, self._draw_bufs = torch.initial_seed(), 0, [None, None]
         elif draws != "reference":
             raise ValueError("draws must be 'reference' (python random + torch CPU generator, the reference's "
-                             "order) or 'device' (device generator)")
+                             "order) or 'device' (one counter-based draw kernel on the device)")
         self.all_indices = list(range(self.N))
         nb = self.plan.local_count
         ws = self.eng.ws
@@ -273,12 +272,18 @@ class DiffusionTrainer:
             i = torch.randint(0, diffusion_steps, size=(B,))
             noise = torch.randn(B, T, K)
         else:
-            idx = torch.randperm(self.N, device=d, generator=self.gen)[:B] if self.N >= B else None
-            if idx is None:
+            if self.N < B:
                 raise ValueError("Sample larger than population or is negative")
-            t = torch.rand(B, T, 1, device=d, generator=self.gen).sort(1)[0]
-            i = torch.randint(0, diffusion_steps, (B,), device=d, generator=self.gen)
-            noise = torch.randn(B, T, K, device=d, generator=self.gen)
+            # one launch (tad_draw_batch): a function of (seed, iteration) alone, so every rank draws the same global
+            # batch; two sets of buffers alternate, so a draw made ahead does not overwrite the one a step still reads
+            bufs = self._draw_bufs[self._draw_count & 1]
+            if bufs is None:
+                bufs = dict(idx=torch.empty(B, dtype=torch.int64, device=d), t=torch.empty(B, T, 1, device=d),
+                            i=torch.empty(B, dtype=torch.int32, device=d), noise=torch.empty(B, T, K, device=d))
+                self._draw_bufs[self._draw_count & 1] = bufs
+            ops.draw_batch(self._draw_seed, self._draw_count, self.N, B, T, K, diffusion_steps, **bufs)
+            self._draw_count += 1
+            return bufs
         return dict(idx=idx, t=t, i=i, noise=noise)
 
     def use_graph(self):

@@ -129,7 +129,7 @@ class FlatParams:
         return self._view(self.gflat, first, rows * cols, (rows, cols))
 
     def zero_grad(self):
-        self.gflat[:self.n_active + self.SLOTS].zero_()
+        ops.zero_(self.gflat[:self.n_active + self.SLOTS])
 
     def slots(self, n=1):
         """n floats right behind the active gradient range (zeroed by zero_grad, reduced with the gradients)."""
@@ -263,7 +263,7 @@ class W16Images:
         if self._ver != self.fp.version:
             ops.pack_w16(self.items)
             for a, b, out in self.sums:
-                torch.add(a, b, out=out)
+                ops.add_vec(a.reshape(-1), b.reshape(-1), out)
             self._ver = self.fp.version
 
 
@@ -289,7 +289,7 @@ class Workspace:
             t = torch.empty(shape, dtype=dtype, device=self.device)
             self.bufs[name] = t
         if zero is True or (zero == "new" and fresh):
-            t.zero_()
+            ops.zero_(t)
         return t
 
     def nbytes(self):
@@ -371,7 +371,7 @@ class RnnStack:
         key = f"{tag}.xpad{layer}"
         fresh = key not in ws.bufs or tuple(ws.bufs[key].shape) != (x.shape[0], npad)
         xp = ws.get(key, (x.shape[0], npad), zero=fresh)        # the pad columns are zeroed once and never written
-        xp[:, :n].copy_(x)
+        ops.copy_2d(x, xp[:, :n])
         return xp
 
     def pack(self, need_bwd=True):
@@ -1142,7 +1142,7 @@ class DenoiserEngine:
         ops.linear_fwd(prec, gout, fp.p("cond_output.weight"), fp.p("cond_output.bias"), cat[:, :H])
         ops.posenc_fwd(t.reshape(BT), 1, BT, H, 1.0, fp.p("t_enc.linear_proj.weight"), fp.p("t_enc.linear_proj.bias"),
                        self.scale_t, self.shift_t, cat[:, H:2 * H])
-        cat[:, 2 * H:3 * H].zero_()
+        ops.zero_(cat[:, 2 * H:3 * H])
         ta = ws.get("ta", (BT, H))
         ops.linear_fwd(prec, time_info.reshape(BT, self.time_dim), fp.p("time_encode.0.weight"), fp.p("time_encode.0.bias"),
                        ta, act=ACT_RELU)

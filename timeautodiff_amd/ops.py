@@ -573,6 +573,46 @@ def gather_rows(src, idx, out):
     _call("tad_gather_rows", rows, row_len, src.data_ptr(), idx.data_ptr(), out.data_ptr(), _stream())
 
 
+def draw_batch(seed, counter, N, B, T, K, n_steps, idx=None, t=None, i=None, noise=None):
+    """The draws of one training iteration on the device (reference DIFF.py:306, 317, 253, 108; tad_draw_batch):
+    idx [B] int64 distinct window indices in [0, N), t [B, T(, 1)] float32 ascending uniforms, i [B] int32 diffusion
+    steps, noise [B, T, K] float32 normals -- functions of (seed, counter) alone.  Outputs left None are not drawn."""
+    for a, dt, n in ((idx, torch.int64, B), (t, torch.float32, B * T), (i, torch.int32, B), (noise, torch.float32, B * T * K)):
+        assert a is None or (a.is_cuda and a.is_contiguous() and a.dtype == dt and a.numel() == n), (dt, n)
+    _call("tad_draw_batch", int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), N, B, T, K, n_steps, _ptr(idx), _ptr(t), _ptr(i), _ptr(noise),
+          _stream())
+
+
+def zero_(t):
+    """t[...] = 0 for a contiguous tensor or a 2-D view with unit column stride (float32 / bfloat16 / int32)."""
+    if t.numel() == 0:
+        return t
+    _chk_dev(t)
+    esz = t.element_size()
+    if t.is_contiguous():
+        rows, row_bytes, ld = 1, t.numel() * esz, t.numel() * esz
+    else:
+        assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+        rows, row_bytes, ld = t.shape[0], t.shape[1] * esz, t.stride(0) * esz
+    _call("tad_zero_2d", rows, row_bytes, t.data_ptr(), ld, _stream(), cost=(0.0, float(rows * row_bytes)))
+    return t
+
+
+def copy_2d(src, dst):
+    """dst[:, :cols] = src (float32, unit column stride)."""
+    sp, rows, cols, lds_ = as2d(src)
+    dp, rows2, cols2, ldd = as2d(dst)
+    assert rows == rows2 and cols == cols2
+    _call("tad_copy_2d", rows, cols, sp, lds_, dp, ldd, _stream(), cost=(0.0, 8.0 * rows * cols))
+
+
+def add_vec(a, b, out):
+    """out = a + b (contiguous float32 vectors)."""
+    assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous() and a.numel() == b.numel() == out.numel()
+    assert a.dtype == b.dtype == out.dtype == torch.float32
+    _call("tad_add_vec", a.numel(), _ptr(a), _ptr(b), _ptr(out), _stream())
+
+
 def gather_windows(table, idx, T, stride, out):
     """out[b, t, :] = table[idx[b] * stride + t, :]: a minibatch of sliding windows cut on the fly from the
     [rows, F] table (reference dataprovider_pypots.py:75-87 + the trainers' index gather); idx int64 on device."""
