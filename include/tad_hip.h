@@ -36,7 +36,8 @@ typedef void* tad_stream_t;
 
 enum { TAD_OK = 0, TAD_ERR_INVALID = 1, TAD_ERR_LAUNCH = 2 };
 enum { TAD_F32 = 0, TAD_BF16 = 1 };
-enum { TAD_ACT_NONE = 0, TAD_ACT_RELU = 1, TAD_ACT_SILU = 2 /* tad_mm16_nt only */ };
+enum { TAD_ACT_NONE = 0, TAD_ACT_RELU = 1, TAD_ACT_SILU = 2 /* tad_mm16_nt only */,
+       TAD_ACT_DSILU = 3 /* tad_mm16_nt only: the result is multiplied by silu'(relu_of) instead of being masked by it */ };
 enum { TAD_CELL_LSTM = 0, TAD_CELL_GRU = 1 };
 
 int tad_abi_version(void);

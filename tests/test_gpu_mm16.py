@@ -52,7 +52,10 @@ def _nt(ops, dev, M, N, K, c16, act=0, res=None, relu=None, bias=True):
         ref = ref.clamp_min(0)
     elif act == 2:
         ref = ref * torch.sigmoid(ref)
-    if U is not None:
+    if U is not None and act == 3:
+        sg = torch.sigmoid(U.double())
+        ref = ref * sg * (1 + U.double() * (1 - sg))
+    elif U is not None:
         ref = ref * (U.double() > 0)
     assert not torch.isnan(C.float()).any()
     assert _rel(C, ref) < (4e-3 if c16 else 1e-5)
@@ -76,6 +79,25 @@ def test_mm16_nt_fused_epilogues(ops, dev, M, N, K):
     _nt(ops, dev, M, N, K, True, act=1, res="f32", relu="bf16")
     _nt(ops, dev, M, N, K, False, act=2, res="bf16", relu="f32")
     _nt(ops, dev, M, N, K, True, act=2)
+    _nt(ops, dev, M, N, K, True, act=3, relu="f32", bias=False)      # the backward of a SiLU as the product's epilogue
+    _nt(ops, dev, M, N, K, False, act=3, relu="f32", bias=False)
+
+
+def test_mm16_nt_dsilu_equals_product_then_silu_bwd(ops, dev):
+    """act = DSILU against the two launches it replaces (product into float32, then tad_silu_bwd): bit-identical."""
+    M, N, K = 1000, 432, 432
+    g = torch.Generator(device=dev).manual_seed(5)
+    A = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    Wp = ops.w16_image(N, K, dev)
+    Wp[:N, :K] = (torch.randn(N, K, device=dev, generator=g) * 0.1).bfloat16()
+    z = torch.randn(M, N, device=dev, generator=g) * 3
+    da, dz_two, dz_one = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.mm16_nt(A, Wp, None, da)
+    ops.silu_bwd(z, da, dz_two)
+    ops.mm16_nt(A, Wp, None, dz_one, act=3, relu_of=z)
+    assert torch.equal(dz_one, dz_two)
+    with pytest.raises(Exception):
+        ops.mm16_nt(A, Wp, None, dz_one, act=3)                        # no pre-activations given
 
 
 def test_mm16_nt_rejects_bad_operands(ops, dev):

@@ -370,8 +370,14 @@ __global__ __launch_bounds__(64 * NT_NW, KS16 <= 36 ? 2 : 1) void mm16_nt_kernel
           if (p.relu) {
             float m[4];
             load4(u_rs, p.relu16, nok ? u_row + (uint32_t)n * (p.relu16 ? 2u : 4u) : OOB, m);
+            if (p.act == TAD_ACT_DSILU) {
+              // backward of a SiLU whose pre-activations the operand holds (the arithmetic of silu_bwd_kernel)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (!(m[j] > 0.f)) v[j] = 0.f;
+              for (int j = 0; j < 4; ++j) { const float s = sigmoid_acc(m[j]); v[j] = v[j] * s * (1.f + m[j] * (1.f - s)); }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) if (!(m[j] > 0.f)) v[j] = 0.f;
+            }
           }
         }
         if (p.c16) {
@@ -703,7 +709,7 @@ extern "C" int tad_mm16_nt(int64_t M, int64_t N, int64_t K, const void* A16, int
   TAD_CHECK(!Z16 || mn_ok(Z16, ldz, TAD_BF16), "tad_mm16_nt: bad Z16");
   TAD_CHECK(!residual || mn_ok(residual, ld_res, res_dtype), "tad_mm16_nt: bad residual");
   TAD_CHECK(!relu_of || mn_ok(relu_of, ld_relu, relu_dtype), "tad_mm16_nt: bad relu_of");
-  TAD_CHECK(act == TAD_ACT_NONE || act == TAD_ACT_RELU || act == TAD_ACT_SILU, "tad_mm16_nt: bad act %d", act);
+  TAD_CHECK(act == TAD_ACT_NONE || act == TAD_ACT_RELU || act == TAD_ACT_SILU || (act == TAD_ACT_DSILU && relu_of), "tad_mm16_nt: bad act %d (TAD_ACT_DSILU needs relu_of)", act);
   TAD_CHECK(lda < (1 << 22) && ldw < (1 << 22) && ldc < (1 << 22) && N * ldw < (1ll << 30), "tad_mm16_nt: leading dimension too large");
   // the [M,N] operands are addressed with 32-bit byte offsets
   TAD_CHECK(M * ldc * 4 < 0xfff00000ll && M * ld_res * 4 < 0xfff00000ll && M * ld_relu * 4 < 0xfff00000ll && M * ldz * 2 < 0xfff00000ll,

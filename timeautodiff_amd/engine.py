@@ -8,7 +8,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
-from .ops import ACT_RELU, BF16, CELL_GRU, CELL_LSTM, F32
+from .ops import ACT_DSILU, ACT_RELU, BF16, CELL_GRU, CELL_LSTM, F32
 
 ALIGN = 64  # floats (256 B)
 # TAD_GRAD_STREAM=1 moves the launches nothing waits for before the optimizer step (weight gradients, table gradients,
@@ -746,11 +746,10 @@ class EmbBlock:
             a1 = ws.get(f"{tag}.a1_16", (rows, 16 * nn), dtype=b16)
             dy1 = ws.get(f"{tag}.dy1_16", (rows, 16 * nn), dtype=b16)
             ops.mm16_nt(da2, img_rows(wt, nd * E, 16 * nn), None, dy1)
-            da1 = ws.get(f"{tag}.da1", (rows, 16 * nn))
-            ops.mm16_nt(dy1, im["n2"]["tr"], None, da1)
             fp.queue_tn(dy1, dict(b=a1, c=fp.g(pre + "mlp_nums.2.weight"), db=fp.g(pre + "mlp_nums.2.bias")))
+            # d(z1) = (dy1 W) * silu'(z1): the SiLU's backward is the product's epilogue (d(a1) never reaches memory)
             dz1 = ws.get(f"{tag}.dz1_16", (rows, 16 * nn), dtype=b16)
-            ops.silu_bwd(z1, da1, dz1)
+            ops.mm16_nt(dy1, im["n2"]["tr"], None, dz1, act=ACT_DSILU, relu_of=z1)
             fp.queue_tn(dz1, dict(b=feats, c=fp.g(pre + "mlp_nums.0.weight"), db=fp.g(pre + "mlp_nums.0.bias")))
 
 

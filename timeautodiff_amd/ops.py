@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, BF16, CELL_GRU, CELL_LSTM, F32, RnnBwdDir, RnnDir  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ACT_DSILU, BF16, CELL_GRU, CELL_LSTM, F32, RnnBwdDir, RnnDir  # noqa: F401
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -266,7 +266,7 @@ def w16_image(n, k, device):
 
 
 def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=None):
-    """c = act(a16 w16[:N, :K]^T + bias + residual), zeroed where relu_of <= 0: a16 [M,K] bfloat16, w16 a padded
+    """c = act(a16 w16[:N, :K]^T + bias + residual), zeroed where relu_of <= 0 (act=ACT_DSILU: multiplied by silu'(relu_of) instead): a16 [M,K] bfloat16, w16 a padded
     bfloat16 weight image (``w16_image``: rows >= N rounded up to 64, columns K rounded up to 128, zeros beyond K),
     c [M,N] float32 or bfloat16, residual / relu_of float32 or bfloat16 [M,N]; z_out (bfloat16) receives the value
     before ``act``."""
