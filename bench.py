@@ -450,8 +450,15 @@ def main():
                 continue
             note(f"denoiser training, {name}")
             o, r, _, keep = bench_denoiser(cx, wl["schema"], wl["T"], wl["H"], wl["big_B"], a.dtype, 5, 2, prime=4, seed=2000)
-            del keep
             o["roofline"] = r
+            # the sampler at this workload's shape: 1024 sequences through all 100 reverse steps
+            m_w, _, ti_w, cond_w = keep
+            tg = torch.linspace(0, 1, wl["T"], device=dev).view(1, -1, 1).repeat(B_SAMPLE, 1, 1)
+            run_w = lambda: DIFF.sample(tg, B_SAMPLE, wl["T"], K, STEPS_DIFF, m_w, ti_w[:B_SAMPLE], cond_w[:B_SAMPLE], None, noise_source="device")  # noqa: E731
+            run_w()
+            ds_w = cx.timed(run_w, 2) / 2
+            o["sampler"] = dict(seqs_per_s=round(B_SAMPLE / ds_w, 1), ms_per_call=round(1e3 * ds_w, 2), batch=B_SAMPLE)
+            del keep, m_w, ti_w, cond_w
             extras["workloads"][name] = o
             torch.cuda.empty_cache()
         for name in ("metro_T48_H512", "airq_T48_H512"):

@@ -361,6 +361,60 @@ def test_rnn_inference_matches_training(ops, dev):
     assert torch.equal(o1, o2)
 
 
+@pytest.mark.parametrize("cell", [0, 1])
+@pytest.mark.parametrize("B,T,H", [(19, 5, 200), (8, 3, 168), (33, 4, 256), (5, 6, 160), (12, 3, 196), (9, 4, 40)])
+def test_rnn_inference_16_row_form(ops, dev, cell, B, T, H):
+    """bf16 launches without a gate stash at 8 rows per workgroup take the 16-row MFMA form of the forward kernel (W_hh
+    in registers + LDS where it fits; H = 40 is below its register-resident k-steps and falls back): h against the
+    oracle (which rounds the operands and stored tensors as the kernels do), the bf16 copy of h against h, and both
+    against the launch WITH a stash (the 32-row form) on the same inputs."""
+    rng = np.random.default_rng(1000 * cell + H)
+    G, nd, IN = (4 if cell == 0 else 3), 2, 8
+    BT, H4, GH = B * T, 4 * H, G * H
+    x = rnd(rng, B, T, IN)
+    k = 1.0 / np.sqrt(H)
+    Wih = rng.uniform(-k, k, (nd, GH, IN)).astype(np.float32)
+    Whh = rng.uniform(-k, k, (nd, GH, H)).astype(np.float32)
+    bih = rng.uniform(-k, k, (nd, GH)).astype(np.float32)
+    bhh = rng.uniform(-k, k, (nd, GH)).astype(np.float32)
+    fwd = ornn.lstm_dir_fwd if cell == 0 else ornn.gru_dir_fwd
+    f64 = lambda a: a.astype(np.float64)
+    with oops.bf16_operands(storage=True):
+        ref = [fwd(f64(x), f64(Wih[d]), f64(Whh[d]), f64(bih[d]), f64(bhh[d]), bool(d))[0].reshape(BT, H) for d in range(nd)]
+    xd = D(x, dev).view(BT, IN)
+    Wihd, Whhd, bihd, bhhd = D(Wih, dev), D(Whh, dev), D(bih, dev), D(bhh, dev)
+    w_gl = torch.empty(nd * H4, IN, dtype=torch.bfloat16, device=dev)
+    bias_gl = torch.empty(nd * H4, device=dev)
+    ops.rnn_pack_input(cell, H, Wihd.view(nd * GH, IN), bihd.view(-1), bhhd.view(-1), w_gl, bias_gl)
+    xproj = torch.zeros(BT, nd * H4, dtype=torch.bfloat16, device=dev)
+    ops.linear_fwd_b16(xd, w_gl, bias_gl, xproj)
+    nbytes = ops.rnn_packed_bytes(1, H, G)
+    pf = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(nd)]
+    for d in range(nd):
+        ops.rnn_pack_weights(1, H, G, Whhd[d], pf[d], None)
+    res = {}
+    for form in ("plain", "stash"):
+        out = torch.full((BT, nd * H), float("nan"), device=dev)
+        out16 = torch.full((BT, nd * H), float("nan"), device=dev, dtype=torch.bfloat16)
+        gates = torch.zeros(BT, nd * H4, dtype=torch.bfloat16, device=dev) if form == "stash" else None
+        cst = torch.zeros(BT, nd * H, device=dev) if (form == "stash" and cell == 0) else None
+        dirs = []
+        for d in range(nd):
+            sl, hl = slice(d * H4, (d + 1) * H4), slice(d * H, (d + 1) * H)
+            dirs.append(dict(xproj=xproj[:, sl], w_packed=pf[d], b_hh=bhhd[d] if cell == 1 else None, out=out[:, hl], out16=out16[:, hl],
+                             gates=gates[:, sl] if gates is not None else None, cstate=cst[:, hl] if cst is not None else None,
+                             reverse=bool(d)))
+        ops.rnn_fwd(cell, 1, B, T, H, dirs)
+        torch.cuda.synchronize()
+        res[form] = (out.cpu().numpy(), out16.float().cpu().numpy())
+    o, o16 = res["plain"]
+    assert not np.isnan(o).any() and not np.isnan(o16).any()
+    for d in range(nd):
+        assert fu.rel_err(o[:, d * H:(d + 1) * H], ref[d]) < BF16_EMU_TOL, ("h", d)
+    assert np.array_equal(o16, torch.from_numpy(o).bfloat16().float().numpy())          # the bf16 copy is h rounded
+    assert fu.rel_err(o, res["stash"][0]) < BF16_EMU_TOL
+
+
 # ------------------------------------------------------------------ elementwise family
 def test_add_noise_and_loss(ops, dev):
     rng = np.random.default_rng(1)

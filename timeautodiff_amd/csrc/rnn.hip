@@ -88,6 +88,33 @@ __global__ void pack_kernel(PackArgs a) {
   a.out[gid] = o;
 }
 
+// Forward image for the 16-row form (v_mfma_f32_16x16x32_bf16): blocks [j][kk][g][nb] of 64 uint4, lane l holds
+// B(k = 32 kk + 8 (l / 16) + e, n = unit 32 j + 16 nb + l % 16 of gate g), e = 0..7; zeros beyond H either way.
+struct Pack16Args {
+  const float* w;   // [G*H, H]
+  uint4* out;
+  int H, G, NJ, nk32;
+};
+__global__ void pack16_kernel(Pack16Args a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = gid & 63;
+  int64_t blk = gid >> 6;
+  if (blk >= (int64_t)a.NJ * a.nk32 * a.G * 2) return;
+  const int nb = (int)(blk & 1); blk >>= 1;
+  const int g = (int)(blk % a.G); blk /= a.G;
+  const int kk = (int)(blk % a.nk32), j = (int)(blk / a.nk32);
+  const int unit = 32 * j + 16 * nb + (lane & 15);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * kk + 8 * (lane >> 4) + e;
+    v[e] = (unit < a.H && k < a.H) ? a.w[((int64_t)g * a.H + unit) * a.H + k] : 0.f;
+  }
+  uint4 o;
+  o.x = pk2(v[0], v[1]); o.y = pk2(v[2], v[3]); o.z = pk2(v[4], v[5]); o.w = pk2(v[6], v[7]);
+  a.out[gid] = o;
+}
+
 // ---------------------------------------------------------------------------
 // acc[n] += A(32 x K from LDS) * B(block stream): blocks ordered [kk][n], 64 uint4 each.  The first kl k-blocks
 // are read from a copy of theirs in LDS (wl, same order), the rest from global memory through a ring of PF
@@ -282,6 +309,7 @@ struct RnnFwdArgs {
   int kl;      // leading k-blocks of every chunk's W_hh image kept in LDS for the whole sequence
   int out16_rows;   // 1: the bf16 copy of h_t is written from the LDS tile in 16-byte pieces (bf16 precision, aligned rows)
   int tile_rows;    // rows of an h tile in LDS: 32, or rpw in the resident form
+  int nk32;         // 16-row form: 32-deep k-steps of its W_hh image
 };
 
 // NKR > 0, the resident form (small batches: rpw <= 16, one chunk per wave, bf16): nothing of W_hh is streamed inside
@@ -494,6 +522,171 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
     atomicAdd(&g_rnn_stamps[3], sGate); atomicAdd(&g_rnn_stamps[4], sBar); atomicAdd(&g_rnn_stamps[7], (unsigned long long)T);
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// The 16-row form of the forward kernel, for launches of 8 batch rows per workgroup without a gate stash (every launch
+// of the sampler at up to 2047 sequences per call; bf16 precision and storage, one chunk of 32 units per wave).  In the
+// 32-row form three quarters of every MFMA there multiply padding and the matrix pipe, shared by the two waves of a
+// SIMD, is the longest phase of the step; v_mfma_f32_16x16x32_bf16 halves that.  The 8 real rows sit at rows
+// {0,1, 4,5, 8,9, 12,13} of the 16-row operand, so that in the result (row = 4 * (lane / 16) + register) every lane
+// keeps two live registers per 16-unit block: the gate math runs on all 64 lanes, four elements each, as before.
+// W_hh is resident: k-steps (32 deep) [0, kl) in LDS, the last NKR in registers (4 VGPRs per k-step, gate and block).
+template <int CELL, int NKR>
+__global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
+  constexpr int G = CELL == TAD_CELL_LSTM ? 4 : 3;
+  typedef Slots<true> SL;
+  typedef typename SL::raw raw_t;
+  typedef __attribute__((ext_vector_type(4))) float f32x4v;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const tad_rnn_dir_t d = a.d[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c16 = lane & 15;
+  const int64_t b0 = (int64_t)blockIdx.x * 8;
+  const size_t buf_bytes = (size_t)8 * a.lds_ld * 2;
+  const int H = a.H, T = a.T;
+  // the 16-row-form image follows the 32-row-form image in the packed buffer
+  const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed) + (int64_t)a.NJ * a.nk * G * 64 + (int64_t)wave * a.nk32 * G * 2 * 64;
+
+  for (size_t i = threadIdx.x; i < 2 * buf_bytes / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  uint4* wl = reinterpret_cast<uint4*>(smem + 2 * buf_bytes) + (size_t)wave * a.kl * G * 2 * 64;
+  uint4 wres[NKR][G][2];
+  if (wave < a.NJ) {
+    for (int i = 0; i < a.kl * G * 2; ++i) wl[i * 64 + lane] = wp[i * 64 + lane];
+#pragma unroll
+    for (int p = 0; p < NKR; ++p)
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) wres[p][g][nb] = wp[(((a.kl + p) * G + g) * 2 + nb) * 64 + lane];
+  }
+  float st[2][2], bh[2][3];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    st[nb][0] = st[nb][1] = 0.f;
+    bh[nb][0] = bh[nb][1] = bh[nb][2] = 0.f;
+    if constexpr (CELL == TAD_CELL_GRU) {
+      const int u = 32 * wave + 16 * nb + c16;
+      if (u < H && d.b_hh) { bh[nb][0] = d.b_hh[u]; bh[nb][1] = d.b_hh[H + u]; bh[nb][2] = d.b_hh[2 * H + u]; }
+    }
+  }
+  __syncthreads();
+
+  // A operand: lane -> operand row lane % 16, real when (row & 3) < 2: batch row 2 * (row / 4) + (row & 1) of the tile
+  const int arow = lane & 15;
+  const bool a_live = (arow & 3) < 2;
+  const uint32_t a_off = (uint32_t)(((a_live ? 2 * (arow >> 2) + (arow & 1) : 0) * a.lds_ld + 8 * q) * 2);
+  // result / gate math: element (nb, e) of the lane = batch row 2 q + e, unit 32 wave + 16 nb + lane % 16
+  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(d.xproj);
+  auto load_xp = [&](int step_, raw_t (&raw)[2][2]) {
+    const int tt_ = d.reverse ? T - 1 - step_ : step_;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int u = 32 * wave + 16 * nb + c16;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int64_t b = b0 + 2 * q + e;
+        const bool ok = u < H && b < a.B;
+        raw[nb][e] = ok ? *reinterpret_cast<const raw_t*>(xbase + ((b * T + tt_) * d.ld_xproj + 4 * u) * 2) : SL::zero();
+      }
+    }
+  };
+  raw_t nraw[2][2];
+  if (wave < a.NJ) load_xp(0, nraw);
+
+  for (int step = 0; step < T; ++step) {
+    const int tt = d.reverse ? T - 1 - step : step;
+    const unsigned char* cur = smem + (size_t)(step & 1) * buf_bytes;
+    unsigned char* nxt = smem + (size_t)((step + 1) & 1) * buf_bytes;
+    if (wave < a.NJ) {
+      f32x4v acc[G][2];
+      float xn[2][2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (e < 2) {
+            const f32x4 v = SL::unpack(nraw[nb][e]);
+            if constexpr (CELL == TAD_CELL_LSTM) {
+              acc[0][nb][e] = v[0]; acc[1][nb][e] = v[1]; acc[2][nb][e] = v[2]; acc[3][nb][e] = v[3];
+            } else {
+              acc[0][nb][e] = v[0]; acc[1][nb][e] = v[1]; acc[2][nb][e] = 0.f; xn[nb][e] = v[2];
+            }
+          } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][nb][e] = 0.f;
+          }
+        }
+      auto afrag = [&](int kk) -> bf16x8 {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(cur + a_off + 64 * kk);
+        if (!a_live) v = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+        return v;
+      };
+      for (int kk = 0; kk < a.kl; ++kk) {
+        const bf16x8 av = afrag(kk);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[((kk * G + g) * 2 + nb) * 64 + lane]), acc[g][nb], 0, 0, 0);
+      }
+      {
+        bf16x8 av[NKR];
+#pragma unroll
+        for (int p = 0; p < NKR; ++p) av[p] = afrag(a.kl + p);
+#pragma unroll
+        for (int p = 0; p < NKR; ++p)
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+              acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[p], __builtin_bit_cast(bf16x8, wres[p][g][nb]), acc[g][nb], 0, 0, 0);
+      }
+      if (step + 1 < T) load_xp(step + 1, nraw);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int u = 32 * wave + 16 * nb + c16;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int row = 2 * q + e;
+          const int64_t b = b0 + row;
+          const bool ok = u < H && b < a.B;
+          float h;
+          if constexpr (CELL == TAD_CELL_LSTM) {
+            const float ig = fast_sigmoid(acc[0][nb][e]), fg = fast_sigmoid(acc[1][nb][e]);
+            const float gg = fast_tanh(acc[2][nb][e]), og = fast_sigmoid(acc[3][nb][e]);
+            const float c = fg * st[nb][e] + ig * gg;
+            st[nb][e] = c;
+            h = og * fast_tanh(c);
+          } else {
+            const float rg = fast_sigmoid(acc[0][nb][e] + bh[nb][0]), zg = fast_sigmoid(acc[1][nb][e] + bh[nb][1]);
+            const float hpn = acc[2][nb][e] + bh[nb][2];
+            const float ng = fast_tanh(xn[nb][e] + rg * hpn);
+            h = (1.f - zg) * ng + zg * st[nb][e];
+            st[nb][e] = h;
+          }
+          if (!ok) h = 0.f;
+          if (u < a.lds_ld) lds_put<true>(nxt, a.lds_ld, row, u, h);
+          if (ok) {
+            if (d.out) d.out[(b * T + tt) * d.ld_out + u] = h;
+            if (d.out16 && !a.out16_rows) reinterpret_cast<bf16_t*>(d.out16)[(b * T + tt) * d.ld_out16 + u] = (bf16_t)h;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (a.out16_rows && d.out16) {
+      const int cpr = H >> 3;
+      const int total = 8 * cpr;
+      for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int row = i / cpr, ch = i - row * cpr;
+        if (b0 + row < a.B) {
+          const uint4 v = *reinterpret_cast<const uint4*>(nxt + ((size_t)row * a.lds_ld + 8 * ch) * 2);
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(d.out16) + ((b0 + row) * (int64_t)T + tt) * d.ld_out16 + 8 * ch) = v;
+        }
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -761,6 +954,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackInArgs a) {
 // ---------------------------------------------------------------------------
 struct Geom {
   int NJ, width, nkf, nkb, jpw, nw;
+  int nk32;      // 32-deep k-steps of the 16-row-form forward image (bf16 precision only)
 };
 
 // Rows of the batch one workgroup owns.  The MFMA tile is 32 rows; when the batch is too
@@ -782,6 +976,7 @@ Geom geom(int prec, int64_t H, int G) {
   g.width = 32 * g.NJ;
   g.nkf = (int)cdiv64(H, ks);
   g.nkb = G * g.width / ks;
+  g.nk32 = prec == TAD_BF16 ? (int)cdiv64(H, 32) : 0;
   g.jpw = g.NJ <= 8 ? 1 : (g.NJ <= 16 ? 2 : 4);
   g.nw = (int)cdiv64(g.NJ, g.jpw);
   return g;
@@ -818,6 +1013,18 @@ int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream
 }
 
 constexpr int RES_NKR = 8;     // k-blocks of W_hh the resident form keeps in registers (4 VGPRs per k-block and gate)
+constexpr int F16_NKR_LSTM = 5, F16_NKR_GRU = 4;   // 32-deep k-steps the 16-row form keeps in registers (8 / 6 blocks of 4 VGPRs each)
+
+template <int CELL, int NKR>
+int launch_fwd16(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+  auto k = rnn_fwd16_kernel<CELL, NKR>;
+  static size_t configured[64] = {};
+  if (int rc = set_lds(k, lds, configured)) return rc;
+  hipLaunchKernelGGL(k, grid, block, lds, s, a);
+  TAD_LAUNCH_CHECK();
+  tad_note_kernel("rnn_fwd16_kernel<%d, %d>", CELL, NKR);
+  return TAD_OK;
+}
 
 constexpr int BWD_NKR = 16;    // k-blocks of the transposed W_hh image the backward keeps in registers (4 VGPRs each)
 
@@ -838,7 +1045,8 @@ int launch_bwd(const RnnBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream
 extern "C" int64_t tad_rnn_packed_bytes(int prec, int64_t H, int G) {
   if (H <= 0 || (G != 3 && G != 4) || (prec != TAD_F32 && prec != TAD_BF16)) return -1;
   const Geom g = geom(prec, H, G);
-  const int64_t f = (int64_t)g.NJ * g.nkf * G, b = (int64_t)g.NJ * g.nkb;
+  // (forward buffer: the 32-row-form image, then in bf16 precision the 16-row-form image)
+  const int64_t f = (int64_t)g.NJ * g.nkf * G + (int64_t)g.NJ * g.nk32 * G * 2, b = (int64_t)g.NJ * g.nkb;
   return (f > b ? f : b) * 1024;
 }
 
@@ -857,6 +1065,14 @@ extern "C" int tad_rnn_pack_weights(int prec, int64_t H, int G, const float* w_h
     const int64_t nblocks = bw ? (int64_t)g.NJ * g.nkb : (int64_t)g.NJ * g.nkf * G;
     const int64_t threads = nblocks * 64;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    TAD_LAUNCH_CHECK();
+  }
+  if (packed_fwd && g.nk32 > 0) {
+    Pack16Args a{};
+    a.w = w_hh; a.out = reinterpret_cast<uint4*>(packed_fwd) + (int64_t)g.NJ * g.nkf * G * 64;
+    a.H = (int)H; a.G = G; a.NJ = g.NJ; a.nk32 = g.nk32;
+    const int64_t threads = (int64_t)g.NJ * g.nk32 * G * 2 * 64;
+    hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, (hipStream_t)stream, a);
     TAD_LAUNCH_CHECK();
   }
   return TAD_OK;
@@ -911,6 +1127,25 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   a.kl = 0;
   dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
+  {
+    // 8 rows per workgroup and no gate stash (the sampler): the 16-row form, if W_hh fits its registers + LDS
+    static const char* f16_env = getenv("TAD_RNN_F16");      // experiments: 0 = never
+    const int nkr = cell == TAD_CELL_LSTM ? F16_NKR_LSTM : F16_NKR_GRU;
+    const int kl = g.nk32 - nkr;
+    const int ld16 = 32 * g.nk32 + 8;
+    const size_t need = (size_t)2 * 8 * ld16 * 2 + (size_t)(kl > 0 ? kl : 0) * g.NJ * G * 2 * 1024;
+    bool plain = true;
+    for (int i = 0; i < ndir; ++i) plain = plain && !dirs[i].gates;
+    if (bf && st16 && g.jpw == 1 && a.rpw == 8 && plain && kl >= 0 && need <= LDS_LIMIT && !(f16_env && atoi(f16_env) == 0)) {
+      RnnFwdArgs b = a;
+      b.kl = kl; b.nk32 = g.nk32; b.lds_ld = ld16; b.tile_rows = 8;
+      b.out16_rows = H % 8 == 0;
+      for (int i = 0; i < ndir; ++i)
+        if (dirs[i].out16 && (dirs[i].ld_out16 % 8 != 0 || (reinterpret_cast<uintptr_t>(dirs[i].out16) & 15) != 0)) b.out16_rows = 0;
+      return cell == TAD_CELL_LSTM ? launch_fwd16<TAD_CELL_LSTM, F16_NKR_LSTM>(b, grid, block, need, s)
+                                   : launch_fwd16<TAD_CELL_GRU, F16_NKR_GRU>(b, grid, block, need, s);
+    }
+  }
   {
     // small batches: the resident form, if the k-blocks that do not fit its registers fit the LDS beside the h tiles
     static const char* res_env = getenv("TAD_RNN_RES");      // experiments: 0 = always the streaming form
