@@ -273,6 +273,9 @@ def img_rows(img, r0, n):
     return img[r0:r0 + -(-n // 64) * 64]
 
 
+_CHUNK_STREAMS = {}      # device -> streams the sampler's concurrent chunks run on, shared by every engine of the process
+
+
 class Workspace:
     """Named device buffers, allocated on first use and reused while the shape is stable."""
 
@@ -1066,7 +1069,7 @@ class DenoiserEngine:
         use_graph = (SAMPLE_GRAPH if graph is None else bool(graph)) and ops.tracing() is None
         if not use_graph:
             while len(self._chunks) < nch:
-                self._chunks.append(self._new_chunk())
+                self._chunks.append(self._new_chunk(len(self._chunks)))
             chunks = self._chunks[:nch] if nch > 1 else [(None, self.ws, None)]
             self._sample_run(x, t, time_info, cond, z_all, coef, chunks)
             return x
@@ -1081,7 +1084,7 @@ class DenoiserEngine:
             static = {k: torch.empty_like(v) for k, v in args.items()}
             for k, v in args.items():
                 static[k].copy_(v)
-            chunks = [self._new_chunk() for _ in range(nch)] if nch > 1 else [(None, Workspace(self.device), None)]
+            chunks = [self._new_chunk(c) for c in range(nch)] if nch > 1 else [(None, Workspace(self.device), None)]
             run = lambda: self._sample_run(static["x"], static["t"], static["time_info"], static["cond"], static["z"],  # noqa: E731
                                            coef, chunks)
             run()                               # sizes the workspaces (and loads the code objects) outside the capture
@@ -1097,8 +1100,14 @@ class DenoiserEngine:
         x.copy_(static["x"])
         return x
 
-    def _new_chunk(self):
-        return torch.cuda.Stream(device=self.device), Workspace(self.device), torch.cuda.Event()
+    def _new_chunk(self, i):
+        """Chunk i of a sampler call: a stream from the process-wide pool of its device (a process has few hardware
+        queues -- four by default: streams of their own per engine made the second model of a process share queues,
+        and its two-chunk loop ran at 39.6 instead of 25.4 ms per 1024 sequences), a workspace and an event of its own."""
+        pool = _CHUNK_STREAMS.setdefault(str(self.device), [])
+        while len(pool) <= i:
+            pool.append(torch.cuda.Stream(device=self.device))
+        return pool[i], Workspace(self.device), torch.cuda.Event()
 
     def _sample_run(self, x, t, time_info, cond, z_all, coef, chunks):
         """Enqueue the reverse loop for x [B,T,K] (in place): one chunk (stream, workspace, event) per contiguous
