@@ -220,8 +220,8 @@ int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, 
 
 /* Bytes of ONE packed buffer (forward or backward) of a recurrent weight matrix W_hh[G*H,H].  In bf16 precision
  * the forward buffer holds two images: the one the 32-row MFMA forms read and, behind it, the one of the 16-row form
- * that launches of 8 batch rows per workgroup without a gate stash take (every reverse step of `sample`,
- * DIFF.py:340-351, at up to 2047 sequences per call). */
+ * that launches of 8 batch rows per workgroup take (every reverse step of `sample`, DIFF.py:340-351, at up to 2047
+ * sequences per call; training at the reference's batch of 100, DIFF.py:305-328). */
 int64_t tad_rnn_packed_bytes(int prec, int64_t H, int G);
 /* Re-lay W_hh[G*H,H] (row stride H) into the MFMA-fragment-ordered images the
  * sequence kernels stream: packed_fwd for h W_hh^T, packed_bwd for dgates W_hh.

@@ -362,12 +362,12 @@ def test_rnn_inference_matches_training(ops, dev):
 
 
 @pytest.mark.parametrize("cell", [0, 1])
-@pytest.mark.parametrize("B,T,H", [(19, 5, 200), (8, 3, 168), (33, 4, 256), (5, 6, 160), (12, 3, 196), (9, 4, 40)])
+@pytest.mark.parametrize("B,T,H", [(19, 5, 200), (8, 3, 168), (33, 4, 256), (5, 6, 160), (12, 3, 196), (9, 4, 40), (4100, 3, 200)])
 def test_rnn_inference_16_row_form(ops, dev, cell, B, T, H):
-    """bf16 launches without a gate stash at 8 rows per workgroup take the 16-row MFMA form of the forward kernel (W_hh
-    in registers + LDS where it fits; H = 40 is below its register-resident k-steps and falls back): h against the
-    oracle (which rounds the operands and stored tensors as the kernels do), the bf16 copy of h against h, and both
-    against the launch WITH a stash (the 32-row form) on the same inputs."""
+    """bf16 launches at 8 rows per workgroup take the 16-row MFMA form of the forward kernel (W_hh in registers + LDS
+    where it fits; H = 40 is below its register-resident k-steps and falls back), with or without a gate stash; full
+    batches (B = 4100) keep the 32-row forms: h against the oracle (which rounds the operands and stored tensors as the kernels do), the bf16
+    copy of h against h, and the launches with and without a stash against each other on the same inputs."""
     rng = np.random.default_rng(1000 * cell + H)
     G, nd, IN = (4 if cell == 0 else 3), 2, 8
     BT, H4, GH = B * T, 4 * H, G * H

@@ -532,8 +532,12 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
 // {0,1, 4,5, 8,9, 12,13} of the 16-row operand, so that in the result (row = 4 * (lane / 16) + register) every lane
 // keeps two live registers per 16-unit block: the gate math runs on all 64 lanes, four elements each, as before.
 // W_hh is resident: k-steps (32 deep) [0, kl) in LDS, the last NKR in registers (4 VGPRs per k-step, gate and block).
-template <int CELL, int NKR>
+// RPW = 16: all 16 rows of the operand are batch rows (four live registers per block); STASH: the launch also writes the
+// gate stash (and the LSTM's cell state) a backward pass reads.
+template <int CELL, int NKR, int RPW = 8, bool STASH = false>
 __global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
+  static_assert(RPW == 8 || RPW == 16, "8 or 16 batch rows per workgroup");
+  constexpr int LIVE = RPW == 16 ? 4 : 2;      // live result registers per 16-unit block
   constexpr int G = CELL == TAD_CELL_LSTM ? 4 : 3;
   typedef Slots<true> SL;
   typedef typename SL::raw raw_t;
@@ -542,8 +546,8 @@ __global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
   const tad_rnn_dir_t d = a.d[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, c16 = lane & 15;
-  const int64_t b0 = (int64_t)blockIdx.x * 8;
-  const size_t buf_bytes = (size_t)8 * a.lds_ld * 2;
+  const int64_t b0 = (int64_t)blockIdx.x * RPW;
+  const size_t buf_bytes = (size_t)RPW * a.lds_ld * 2;
   const int H = a.H, T = a.T;
   // the 16-row-form image follows the 32-row-form image in the packed buffer
   const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed) + (int64_t)a.NJ * a.nk * G * 64 + (int64_t)wave * a.nk32 * G * 2 * 64;
@@ -560,10 +564,11 @@ __global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) wres[p][g][nb] = wp[(((a.kl + p) * G + g) * 2 + nb) * 64 + lane];
   }
-  float st[2][2], bh[2][3];
+  float st[2][LIVE], bh[2][3];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
-    st[nb][0] = st[nb][1] = 0.f;
+#pragma unroll
+    for (int e = 0; e < LIVE; ++e) st[nb][e] = 0.f;
     bh[nb][0] = bh[nb][1] = bh[nb][2] = 0.f;
     if constexpr (CELL == TAD_CELL_GRU) {
       const int u = 32 * wave + 16 * nb + c16;
@@ -574,24 +579,24 @@ __global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
 
   // A operand: lane -> operand row lane % 16, real when (row & 3) < 2: batch row 2 * (row / 4) + (row & 1) of the tile
   const int arow = lane & 15;
-  const bool a_live = (arow & 3) < 2;
-  const uint32_t a_off = (uint32_t)(((a_live ? 2 * (arow >> 2) + (arow & 1) : 0) * a.lds_ld + 8 * q) * 2);
+  const bool a_live = RPW == 16 || (arow & 3) < 2;
+  const uint32_t a_off = (uint32_t)(((RPW == 16 ? arow : (a_live ? 2 * (arow >> 2) + (arow & 1) : 0)) * a.lds_ld + 8 * q) * 2);
   // result / gate math: element (nb, e) of the lane = batch row 2 q + e, unit 32 wave + 16 nb + lane % 16
   const unsigned char* xbase = reinterpret_cast<const unsigned char*>(d.xproj);
-  auto load_xp = [&](int step_, raw_t (&raw)[2][2]) {
+  auto load_xp = [&](int step_, raw_t (&raw)[2][LIVE]) {
     const int tt_ = d.reverse ? T - 1 - step_ : step_;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int u = 32 * wave + 16 * nb + c16;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int64_t b = b0 + 2 * q + e;
+      for (int e = 0; e < LIVE; ++e) {
+        const int64_t b = b0 + LIVE * q + e;
         const bool ok = u < H && b < a.B;
         raw[nb][e] = ok ? *reinterpret_cast<const raw_t*>(xbase + ((b * T + tt_) * d.ld_xproj + 4 * u) * 2) : SL::zero();
       }
     }
   };
-  raw_t nraw[2][2];
+  raw_t nraw[2][LIVE];
   if (wave < a.NJ) load_xp(0, nraw);
 
   for (int step = 0; step < T; ++step) {
@@ -600,12 +605,12 @@ __global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
     unsigned char* nxt = smem + (size_t)((step + 1) & 1) * buf_bytes;
     if (wave < a.NJ) {
       f32x4v acc[G][2];
-      float xn[2][2];
+      float xn[2][LIVE];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (e < 2) {
+          if (e < LIVE) {
             const f32x4 v = SL::unpack(nraw[nb][e]);
             if constexpr (CELL == TAD_CELL_LSTM) {
               acc[0][nb][e] = v[0]; acc[1][nb][e] = v[1]; acc[2][nb][e] = v[2]; acc[3][nb][e] = v[3];
@@ -647,29 +652,38 @@ __global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
       for (int nb = 0; nb < 2; ++nb) {
         const int u = 32 * wave + 16 * nb + c16;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int row = 2 * q + e;
+        for (int e = 0; e < LIVE; ++e) {
+          const int row = LIVE * q + e;
           const int64_t b = b0 + row;
           const bool ok = u < H && b < a.B;
           float h;
+          raw_t sv;
+          float cst = 0.f;
           if constexpr (CELL == TAD_CELL_LSTM) {
             const float ig = fast_sigmoid(acc[0][nb][e]), fg = fast_sigmoid(acc[1][nb][e]);
             const float gg = fast_tanh(acc[2][nb][e]), og = fast_sigmoid(acc[3][nb][e]);
             const float c = fg * st[nb][e] + ig * gg;
             st[nb][e] = c;
             h = og * fast_tanh(c);
+            cst = c;
+            sv = SL::pack(ig, fg, gg, og);
           } else {
             const float rg = fast_sigmoid(acc[0][nb][e] + bh[nb][0]), zg = fast_sigmoid(acc[1][nb][e] + bh[nb][1]);
             const float hpn = acc[2][nb][e] + bh[nb][2];
             const float ng = fast_tanh(xn[nb][e] + rg * hpn);
             h = (1.f - zg) * ng + zg * st[nb][e];
             st[nb][e] = h;
+            sv = SL::pack(rg, zg, ng, hpn);
           }
           if (!ok) h = 0.f;
           if (u < a.lds_ld) lds_put<true>(nxt, a.lds_ld, row, u, h);
           if (ok) {
             if (d.out) d.out[(b * T + tt) * d.ld_out + u] = h;
             if (d.out16 && !a.out16_rows) reinterpret_cast<bf16_t*>(d.out16)[(b * T + tt) * d.ld_out16 + u] = (bf16_t)h;
+            if constexpr (STASH) {
+              *reinterpret_cast<raw_t*>(reinterpret_cast<unsigned char*>(d.gates) + ((b * T + tt) * d.ld_gates + 4 * u) * 2) = sv;
+              if constexpr (CELL == TAD_CELL_LSTM) d.cstate[(b * T + tt) * d.ld_c + u] = cst;
+            }
           }
         }
       }
@@ -677,7 +691,7 @@ __global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
     __syncthreads();
     if (a.out16_rows && d.out16) {
       const int cpr = H >> 3;
-      const int total = 8 * cpr;
+      const int total = RPW * cpr;
       for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int row = i / cpr, ch = i - row * cpr;
         if (b0 + row < a.B) {
@@ -1015,14 +1029,14 @@ int launch_fwd(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream
 constexpr int RES_NKR = 8;     // k-blocks of W_hh the resident form keeps in registers (4 VGPRs per k-block and gate)
 constexpr int F16_NKR_LSTM = 5, F16_NKR_GRU = 4;   // 32-deep k-steps the 16-row form keeps in registers (8 / 6 blocks of 4 VGPRs each)
 
-template <int CELL, int NKR>
+template <int CELL, int NKR, int RPW = 8, bool STASH = false>
 int launch_fwd16(const RnnFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-  auto k = rnn_fwd16_kernel<CELL, NKR>;
+  auto k = rnn_fwd16_kernel<CELL, NKR, RPW, STASH>;
   static size_t configured[64] = {};
   if (int rc = set_lds(k, lds, configured)) return rc;
   hipLaunchKernelGGL(k, grid, block, lds, s, a);
   TAD_LAUNCH_CHECK();
-  tad_note_kernel("rnn_fwd16_kernel<%d, %d>", CELL, NKR);
+  tad_note_kernel("rnn_fwd16_kernel<%d, %d, %d, %s>", CELL, NKR, RPW, STASH ? "true" : "false");
   return TAD_OK;
 }
 
@@ -1128,22 +1142,32 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
   {
-    // 8 rows per workgroup and no gate stash (the sampler): the 16-row form, if W_hh fits its registers + LDS
-    static const char* f16_env = getenv("TAD_RNN_F16");      // experiments: 0 = never
+    // The 16-row form, if W_hh fits its registers + LDS, at 8 rows per workgroup: the sampler, and training at the
+    // reference's batch of 100 (LSTM 80 -> 64 us, GRU 66 -> 57 us per launch).  (The training GRU at full batches as two
+    // rounds of 16-row workgroups in this form measured the same 217 us as its 32-row resident form: there the step is
+    // bound by its stores and gate math, not by the matrix pipe.)
+    static const char* f16_env = getenv("TAD_RNN_F16");      // experiments: 0 = never, 1 = only without a stash
+    const int f16 = f16_env ? atoi(f16_env) : 2;
     const int nkr = cell == TAD_CELL_LSTM ? F16_NKR_LSTM : F16_NKR_GRU;
     const int kl = g.nk32 - nkr;
     const int ld16 = 32 * g.nk32 + 8;
-    const size_t need = (size_t)2 * 8 * ld16 * 2 + (size_t)(kl > 0 ? kl : 0) * g.NJ * G * 2 * 1024;
-    bool plain = true;
-    for (int i = 0; i < ndir; ++i) plain = plain && !dirs[i].gates;
-    if (bf && st16 && g.jpw == 1 && a.rpw == 8 && plain && kl >= 0 && need <= LDS_LIMIT && !(f16_env && atoi(f16_env) == 0)) {
+    bool stash = false, all_stash = true;
+    for (int i = 0; i < ndir; ++i) { stash = stash || dirs[i].gates; all_stash = all_stash && dirs[i].gates; }
+    const int rpw = a.rpw;
+    const size_t need = (size_t)2 * rpw * ld16 * 2 + (size_t)(kl > 0 ? kl : 0) * g.NJ * G * 2 * 1024;
+    const bool shape_ok = rpw == 8;
+    if (bf && st16 && g.jpw == 1 && shape_ok && (!stash || (all_stash && f16 >= 2)) && kl >= 0 && need <= LDS_LIMIT && f16 >= 1) {
       RnnFwdArgs b = a;
-      b.kl = kl; b.nk32 = g.nk32; b.lds_ld = ld16; b.tile_rows = 8;
+      b.rpw = rpw; b.kl = kl; b.nk32 = g.nk32; b.lds_ld = ld16; b.tile_rows = rpw;
       b.out16_rows = H % 8 == 0;
       for (int i = 0; i < ndir; ++i)
         if (dirs[i].out16 && (dirs[i].ld_out16 % 8 != 0 || (reinterpret_cast<uintptr_t>(dirs[i].out16) & 15) != 0)) b.out16_rows = 0;
-      return cell == TAD_CELL_LSTM ? launch_fwd16<TAD_CELL_LSTM, F16_NKR_LSTM>(b, grid, block, need, s)
-                                   : launch_fwd16<TAD_CELL_GRU, F16_NKR_GRU>(b, grid, block, need, s);
+      dim3 grid16((unsigned)cdiv64(B, rpw), (unsigned)ndir);
+      if (cell == TAD_CELL_LSTM)
+        return stash ? launch_fwd16<TAD_CELL_LSTM, F16_NKR_LSTM, 8, true>(b, grid16, block, need, s)
+                     : launch_fwd16<TAD_CELL_LSTM, F16_NKR_LSTM, 8, false>(b, grid16, block, need, s);
+      return stash ? launch_fwd16<TAD_CELL_GRU, F16_NKR_GRU, 8, true>(b, grid16, block, need, s)
+                   : launch_fwd16<TAD_CELL_GRU, F16_NKR_GRU, 8, false>(b, grid16, block, need, s);
     }
   }
   {
