@@ -371,9 +371,10 @@ __global__ __launch_bounds__(64 * NT_NW, KS16 <= 36 ? 2 : 1) void mm16_nt_kernel
             float m[4];
             load4(u_rs, p.relu16, nok ? u_row + (uint32_t)n * (p.relu16 ? 2u : 4u) : OOB, m);
             if (p.act == TAD_ACT_DSILU) {
-              // backward of a SiLU whose pre-activations the operand holds (the arithmetic of silu_bwd_kernel)
+              // backward of a SiLU whose pre-activations the operand holds (the arithmetic of silu_bwd_kernel, with the
+              // sigmoid on the hardware exp / reciprocal units: 2e-7 absolute, far below the bf16 operands of this product)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) { const float s = sigmoid_acc(m[j]); v[j] = v[j] * s * (1.f + m[j] * (1.f - s)); }
+              for (int j = 0; j < 4; ++j) { const float s = fast_sigmoid(m[j]); v[j] = v[j] * s * (1.f + m[j] * (1.f - s)); }
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) if (!(m[j] > 0.f)) v[j] = 0.f;
