@@ -334,6 +334,19 @@ def test_rnn_fwd_bwd(ops, dev, cell, prec, B, T, H, IN):
     _check_rnn(r, cell, B, T, H, F32_TOL if prec == 0 else BF16_EMU_TOL)
 
 
+@pytest.mark.parametrize("cell", [0, 1])
+def test_rnn_full_batch_forms(ops, dev, cell):
+    """At 4096+ windows per launch the sequence kernels take other forms than at the small batches above (bf16: the
+    LSTM forward as two rounds of 16-row workgroups with resident W_hh, the GRU forward at 32 rows with resident W_hh,
+    the backward at 32 rows with most of the transposed W_hh in LDS and registers): the same outputs, stash and
+    gradients against the oracle, on a batch that leaves the last workgroup ragged."""
+    B, T, H, IN = 4100, 2, 200, 24
+    rng = np.random.default_rng(4100 + cell)
+    r = _run_rnn(ops, dev, cell, 1, B, T, H, [False, True], rng, IN=IN)
+    assert r["s16"]
+    _check_rnn(r, cell, B, T, H, BF16_EMU_TOL)
+
+
 def test_rnn_bwd_phased_path(ops, dev):
     """fp32 LSTM with H = 320: the gate-gradient tile exceeds LDS and the backward kernel
     stages it gate by gate."""
