@@ -132,7 +132,15 @@ def cpu_baseline(seconds_budget=20.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 64:
             break
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or torch.get_num_threads()
+    # the threads numpy's BLAS actually runs its products on (the oracle is numpy; everything else in it is one thread)
+    threads = 0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([int(lib.get("num_threads", 0)) for lib in threadpool_info() if lib.get("user_api") == "blas"] or [0])
+    except Exception:                       # noqa: BLE001 -- reporting only
+        threads = 0
+    if threads <= 0:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or torch.get_num_threads()
     return dict(value=round(n * Bc / el, 2), unit="samples/s", cores=threads, kind="port",
                 sample=f"{n} training steps of the numpy oracle on {Bc}-window batches (T={T}, H={H}, F={F}), {el:.1f} s")
 

@@ -355,6 +355,14 @@ int tad_gather_rows(int64_t rows, int64_t row_len, const float* src, const int64
 int tad_draw_batch(uint64_t seed, uint64_t counter, int64_t N, int64_t B, int64_t T, int64_t K, int n_steps,
                    int64_t* idx, float* t, int32_t* i_idx, float* noise, tad_stream_t stream);
 
+/* The noise of the reverse loop for `noise_source="device"` (DIFF.py:335 `x = torch.randn(B, T, F)`, DIFF.py:347
+ * `z = torch.randn(B, T, F)` once per step): out[r, k], r < rows, k < K = standard normals of rows row0 + r of the
+ * GLOBAL [B*T, K] tensor at step `counter` (< 2^32; the caller uses the step index, and the number of steps for x_T) --
+ * counter-based like tad_draw_batch, so a rank or a concurrent chunk draws exactly its rows, one step at a time,
+ * instead of the whole [steps, B, T, F] block up front.  Not the reference's values (`noise_source="reference"` replays
+ * its CPU generator). */
+int tad_sampler_noise(uint64_t seed, uint64_t counter, int64_t row0, int64_t rows, int K, float* out, tad_stream_t stream);
+
 /* `optimizer.zero_grad()` over the flat gradient buffer (DIFF.py:321, VAE.py:343) and the other clears of a step
  * (an unused column block of the concatenated encodings, DIFF.py:200-203 with the step encoding left out): zero
  * `rows` rows of `row_bytes` bytes, `ld_bytes` apart (4-byte granularity). */

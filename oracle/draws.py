@@ -11,7 +11,7 @@ import numpy as np
 M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = 0x9E3779B9, 0xBB67AE85
 MASK = np.uint64(0xFFFFFFFF)
-ST_PERM, ST_T, ST_I, ST_NOISE = 0, 1, 2, 3
+ST_PERM, ST_T, ST_I, ST_NOISE, ST_SAMPLER = 0, 1, 2, 3, 4
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -96,3 +96,17 @@ def draw_batch(seed, counter, N, B, T, K, n_steps):
     z[:, 0::2] = r * np.cos(th, dtype=np.float32)
     z[:, 1::2] = r * np.sin(th, dtype=np.float32)
     return dict(idx=idx, t=t, i=i, noise=z[:, :n].reshape(B, T, K))
+
+
+def sampler_noise(seed, counter, row0, rows, K):
+    """-> [rows, K] float32: the sampler's noise of global rows row0 .. row0+rows at step ``counter``."""
+    P = (K + 1) // 2
+    r = np.arange(rows, dtype=np.uint64)[:, None]
+    p = np.arange(P, dtype=np.uint64)[None, :]
+    d = _draw(seed, counter, ST_SAMPLER, (np.uint64(row0) + r) * np.uint64(P) + p)
+    rad = np.sqrt(np.float32(-2.0) * np.log(u01_open(d[0]), dtype=np.float32), dtype=np.float32)
+    th = np.float32(6.283185307179586) * u01(d[1])
+    z = np.empty((rows, 2 * P), dtype=np.float32)
+    z[:, 0::2] = rad * np.cos(th, dtype=np.float32)
+    z[:, 1::2] = rad * np.sin(th, dtype=np.float32)
+    return z[:, :K]

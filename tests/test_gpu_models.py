@@ -427,6 +427,40 @@ def test_sampler_fullsize_sharding_invariance(dev):
     assert torch.equal(xg2, x.flip(0))
 
 
+def test_sampler_device_noise_is_counter_based(dev):
+    """noise_source="device": every step's noise is drawn on the device when the step runs, as a function of (seed, step,
+    global row) -- the result equals the loop on the explicitly staged tensors of the same values, whatever the chunking,
+    with or without graph replay, and for a slice of the batch (the rows a second rank would own)."""
+    from timeautodiff_amd import DIFF, ops
+    s = dict(n_bins=0, n_cats=1, n_nums=27, cards=[8])
+    B, T, K, H, S = 600, 24, 6, 200, 100
+    data = fu.make_data(s, N=B, T=T, K=K, seed=3, mask_kind="ones")
+    torch.manual_seed(11)
+    m = DIFF.BiRNN_score(K, 28, H, 2, S, 8, 128, 0, 1, 27, [8])
+    m.set_compute_dtype("bf16")
+    tgrid = torch.linspace(0, 1, T).view(1, -1, 1).repeat(B, 1, 1)
+    ti, cond = torch.from_numpy(data["time_info"]), torch.from_numpy(data["data"])
+    seed = torch.initial_seed()
+    x_T = torch.empty(B, T, K, device=dev)
+    ops.sampler_noise(seed, S, 0, B * T, K, x_T)
+    z = torch.empty(S, B, T, K, device=dev)
+    for st in range(S):
+        ops.sampler_noise(seed, st, 0, B * T, K, z[st])
+    ref = DIFF.sample(tgrid, B, T, K, S, m, ti, cond, None, noise=dict(x_T=x_T, z=z), streams=1)
+    assert torch.isfinite(ref).all()
+    for kw in (dict(streams=1), dict(streams=2), dict(streams=2, graph=True), dict(streams=2, graph=True)):
+        x = DIFF.sample(tgrid, B, T, K, S, m, ti, cond, None, noise_source="device", **kw)
+        assert torch.equal(x, ref), kw
+    # the second half of the batch alone, as the rows of a second rank: same values as in the whole batch
+    lo = 300
+    xT2 = torch.empty(B - lo, T, K, device=dev)
+    ops.sampler_noise(seed, S, lo * T, (B - lo) * T, K, xT2)
+    assert torch.equal(xT2, x_T[lo:])
+    # another seed, another sample
+    torch.manual_seed(12)
+    assert not torch.equal(DIFF.sample(tgrid, B, T, K, S, m, ti, cond, None, noise_source="device"), ref)
+
+
 def test_train_diffusion_on_windowed_tables_equals_stacked_tensors(dev):
     """time_info / cond handed over as WindowedTable views of their [rows, F] tables (windows cut per minibatch
     on the device) train like the reference's stacked [N, T, F] tensors: same loss curve and weights."""

@@ -977,6 +977,25 @@ def test_draw_batch_vs_oracle(ops, dev, N, B, T, K):
         ops.draw_batch(seed, counter, B - 1, B, T, K, 100, idx=idx)             # fewer windows than the sample
 
 
+@pytest.mark.parametrize("rows,K,row0", [(1, 1, 0), (1000, 6, 0), (777, 5, 12345), (4096 * 24, 6, 2 ** 33)])
+def test_sampler_noise_vs_oracle(ops, dev, rows, K, row0):
+    """tad_sampler_noise against its numpy restatement (2e-6 absolute: log / sin / cos), and a slice of the rows equals
+    the same rows drawn on their own (what makes sharded sampling independent of the sharding)."""
+    from oracle import draws
+    seed, step = 0xFEDCBA9876543210, 57
+    out = torch.empty(rows, K, device=dev)
+    ops.sampler_noise(seed, step, row0, rows, K, out)
+    ref = draws.sampler_noise(seed, step, row0, rows, K)
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+    h = rows // 3
+    part = torch.empty(rows - h, K, device=dev)
+    ops.sampler_noise(seed, step, row0 + h, rows - h, K, part)
+    assert torch.equal(part, out[h:])
+    other = torch.empty(rows, K, device=dev)
+    ops.sampler_noise(seed, step + 1, row0, rows, K, other)
+    assert rows * K < 4 or not torch.equal(other, out)
+
+
 def test_zero_copy_add_helpers(ops, dev):
     """The fills / copies of a step (zero_grad, pad columns, the bias of a fused product) against torch."""
     for n in (1, 3, 4, 5, 1027, 3476297):

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import ops
 from .dist import DataParallelPlan
-from .engine import DenoiserEngine, prec_of
+from .engine import CounterNoise, DenoiserEngine, prec_of
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
@@ -476,10 +476,13 @@ def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, 
             z_cpu[s] = torch.randn(B, T, F)[lo:hi]
         z_all = z_cpu.to(d)
     elif noise_source == "device":
-        gen = torch.Generator(device=d)
-        gen.manual_seed(torch.initial_seed())
-        x = torch.randn(B, T, F, device=d, generator=gen)[lo:hi].contiguous()
-        z_all = torch.randn(S, B, T, F, device=d, generator=gen)[:, lo:hi].contiguous()
+        # counter-based noise on the device, seeded like torch's generators: x_T now (counter = S), each step's z when
+        # the step runs, and only the rows this rank (and each of its concurrent chunks) owns -- never the
+        # [S, B, T, F] block.  A function of (seed, step, global row): the result does not depend on the sharding.
+        seed = torch.initial_seed()
+        x = torch.empty(nb, T, F, device=d)
+        ops.sampler_noise(seed, S, lo * T, nb * T, F, x)
+        z_all = CounterNoise(seed, S, lo * T)
     else:
         raise ValueError("noise_source must be 'reference' or 'device'")
 

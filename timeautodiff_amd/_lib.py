@@ -86,6 +86,7 @@ PROTOTYPES = {
     "tad_layernorm_bwd": (_i, [_i64, _i, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
     "tad_gather_rows": (_i, [_i64, _i64, _p, _p, _p, _p]),
     "tad_draw_batch": (_i, [C.c_uint64, C.c_uint64, _i64, _i64, _i64, _i64, _i, _p, _p, _p, _p, _p]),
+    "tad_sampler_noise": (_i, [C.c_uint64, C.c_uint64, _i64, _i64, _i, _p, _p]),
     "tad_zero_2d": (_i, [_i64, _i64, _p, _i64, _p]),
     "tad_copy_2d": (_i, [_i64, _i64, _p, _i64, _p, _i64, _p]),
     "tad_add_vec": (_i, [_i64, _p, _p, _p, _p]),

@@ -25,7 +25,7 @@ __device__ __forceinline__ u4 philox4x32_10(u4 c, uint32_t k0, uint32_t k1) {
 }
 
 // the streams of one draw: counter word 2 of the Philox input
-enum { ST_PERM = 0, ST_T = 1, ST_I = 2, ST_NOISE = 3 };
+enum { ST_PERM = 0, ST_T = 1, ST_I = 2, ST_NOISE = 3, ST_SAMPLER = 4 };
 
 struct DrawArgs {
   uint32_t k0, k1, counter;     // key = seed, counter word 3 = the iteration
@@ -102,6 +102,25 @@ __global__ __launch_bounds__(64) void draw_batch_kernel(DrawArgs a) {
   }
 }
 
+// Noise of one reverse step of the sampler for rows row0 .. row0 + rows of the GLOBAL [B*T, K] latent tensor: value k of
+// global row g comes from draw (g * ceil(K/2) + k/2) of the step's counter -- a function of (seed, step, g, k) alone, so
+// a rank or a chunk that owns any slice of the batch draws exactly its rows, one step at a time.
+__global__ void sampler_noise_kernel(uint32_t k0, uint32_t k1, uint32_t counter, int64_t row0, int64_t rows, int K, float* __restrict__ out) {
+  const int P = (K + 1) >> 1;
+  const int64_t n = rows * P;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / P;
+    const int p = (int)(e - r * P);
+    const uint64_t ge = (uint64_t)((row0 + r) * P + p);
+    const u4 d = philox4x32_10(u4{(uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)ST_SAMPLER, counter}, k0, k1);
+    const float rad = sqrtf(-2.0f * logf(u01_open(d.x)));
+    float s, c;
+    sincosf(6.283185307179586f * u01(d.y), &s, &c);
+    out[r * K + 2 * p] = rad * c;
+    if (2 * p + 1 < K) out[r * K + 2 * p + 1] = rad * s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- fills and copies
 // rows x row_words 32-bit words, row stride ld words (buffers of any 4-byte or 2 x 2-byte element type)
 __global__ void zero_2d_kernel(int64_t rows, int64_t row_words, int64_t ld, uint32_t* __restrict__ p) {
@@ -153,6 +172,16 @@ extern "C" int tad_draw_batch(uint64_t seed, uint64_t counter, int64_t N, int64_
   a.half_bits = (bits + 1) / 2;
   a.idx = idx; a.t = T > 0 ? t : nullptr; a.i = i_idx; a.noise = (T > 0 && K > 0) ? noise : nullptr;
   hipLaunchKernelGGL(draw_batch_kernel, dim3((unsigned)B), dim3(64), (size_t)(T > 0 ? T : 1) * 4, (hipStream_t)stream, a);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_sampler_noise(uint64_t seed, uint64_t counter, int64_t row0, int64_t rows, int K, float* out, tad_stream_t stream) {
+  TAD_CHECK(rows >= 0 && row0 >= 0 && K >= 1 && counter < (1ull << 32), "tad_sampler_noise: bad arguments rows=%ld row0=%ld K=%d", (long)rows, (long)row0, K);
+  if (rows == 0) return TAD_OK;
+  TAD_CHECK(out, "tad_sampler_noise: null pointer");
+  hipLaunchKernelGGL(sampler_noise_kernel, dim3(grid_for(rows * ((K + 1) / 2))), dim3(256), 0, (hipStream_t)stream, (uint32_t)seed, (uint32_t)(seed >> 32),
+                     (uint32_t)counter, row0, rows, K, out);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

@@ -276,6 +276,21 @@ def img_rows(img, r0, n):
 _CHUNK_STREAMS = {}      # device -> streams the sampler's concurrent chunks run on, shared by every engine of the process
 
 
+class CounterNoise:
+    """The noise of a reverse loop as a function instead of a [steps, B, T, K] tensor: step s of global rows row0 ..
+    is drawn when the step needs it (tad_sampler_noise), by whoever owns those rows -- a rank, a concurrent chunk."""
+
+    def __init__(self, seed, steps, row0=0):
+        self.seed, self.steps, self.row0 = int(seed), int(steps), int(row0)
+        self.shape = (self.steps,)
+
+    def rows_from(self, first_row):
+        return CounterNoise(self.seed, self.steps, self.row0 + int(first_row))
+
+    def key(self):
+        return ("counter", self.seed, self.steps, self.row0)
+
+
 class Workspace:
     """Named device buffers, allocated on first use and reused while the shape is stable."""
 
@@ -1042,7 +1057,8 @@ class DenoiserEngine:
     # -- reverse diffusion --------------------------------------------------
     def sample_loop(self, x, t, time_info, cond, z_all, betas, alphas, keep=None, streams=None, graph=None):
         """The reverse-diffusion loop of reference DIFF.py:340-351, in place on x [B,T,K].
-        z_all[s] is the noise of step s.  Everything that does not depend on x or on the
+        z_all[s] is the noise of step s (a [steps, B, T, K] tensor, or a CounterNoise that draws each step's rows on
+        the device when the step runs).  Everything that does not depend on x or on the
         step (cond path, t_enc, time_encode and their share of `proj`) is evaluated once;
         i_enc's share of `proj` is a [steps, H] table used as a per-step bias.
 
@@ -1077,16 +1093,19 @@ class DenoiserEngine:
         # enqueues a single graph launch instead of thousands of kernels (for callers whose host thread is busy).
         # A graph holds the addresses of everything it touches: its inputs are copied into buffers of its own and
         # its chunks work in workspaces of their own, which nothing else resizes.
-        key = (B, T, K, S, nch, self.prec, tuple(time_info.shape), tuple(cond.shape))
+        counter = isinstance(z_all, CounterNoise)
+        key = (B, T, K, S, nch, self.prec, tuple(time_info.shape), tuple(cond.shape), z_all.key() if counter else None)
         ent = self._graphs.get(key)
-        args = dict(x=x, t=t, time_info=time_info, cond=cond, z=z_all)
+        args = dict(x=x, t=t, time_info=time_info, cond=cond)
+        if not counter:
+            args["z"] = z_all
         if ent is None:
             static = {k: torch.empty_like(v) for k, v in args.items()}
             for k, v in args.items():
                 static[k].copy_(v)
             chunks = [self._new_chunk(c) for c in range(nch)] if nch > 1 else [(None, Workspace(self.device), None)]
-            run = lambda: self._sample_run(static["x"], static["t"], static["time_info"], static["cond"], static["z"],  # noqa: E731
-                                           coef, chunks)
+            run = lambda: self._sample_run(static["x"], static["t"], static["time_info"], static["cond"],  # noqa: E731
+                                           z_all if counter else static["z"], coef, chunks)
             run()                               # sizes the workspaces (and loads the code objects) outside the capture
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -1128,7 +1147,8 @@ class DenoiserEngine:
             lo, hi = (B * c) // nch, (B * (c + 1)) // nch
             stream.wait_event(fork)
             with torch.cuda.stream(stream):
-                states.append(self._sample_setup(x[lo:hi], t[lo:hi], time_info[lo:hi], cond[lo:hi], z_all[:, lo:hi], ws))
+                zc = z_all.rows_from(lo * x.shape[1]) if isinstance(z_all, CounterNoise) else z_all[:, lo:hi]
+                states.append(self._sample_setup(x[lo:hi], t[lo:hi], time_info[lo:hi], cond[lo:hi], zc, ws))
         for s in range(S - 1, -1, -1):
             for c in range(nch):
                 with torch.cuda.stream(chunks[c][0]):
@@ -1180,15 +1200,25 @@ class DenoiserEngine:
         return dict(x2=x2, B=B, T=T, ws=ws, pinv=pinv, V=V, wp=wp, z=z_all, xh=xh, pa=ws.get("pa", (BT, H)),
                     ln=ws.get("ln", (BT, 2 * H)), pred=ws.get("pred", (BT, K)), fused=fused, b16=b16, xh16=xh16, pa16=pa16)
 
+    def _step_noise(self, st, s):
+        """Noise of reverse step s for the state's sequences: a row of the staged tensor, or drawn now."""
+        z = st["z"]
+        if isinstance(z, CounterNoise):
+            buf = st["ws"].get("s.z", (st["B"], st["T"], self.K))
+            ops.sampler_noise(z.seed, s, z.row0, st["B"] * st["T"], self.K, buf)
+            return buf
+        return z[s]
+
     def _sample_step(self, st, s, coef):
         """Reverse step s for the sequences of one ``_sample_setup`` state, on the current stream."""
         fp, prec, H = self.fp, self.prec, self.H
         x2, xh, pa, ln, pred = st["x2"], st["xh"], st["pa"], st["ln"], st["pred"]
+        zs = self._step_noise(st, s)
         if st["b16"]:
             ops.mm16_nt(st["xh16"], self.im["proj_x"]["fwd"], st["V"][s], st["pa16"], act=ACT_RELU, residual=st["pinv"])
             lout = self.lstm.forward(st["pa16"], st["B"], st["T"], st["ws"], "lstm", False)
             ops.sampler_tail(prec, lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), fp.p("fc.weight"), fp.p("fc.bias"),
-                             x2, st["z"][s], coef[0][s], coef[1][s], coef[2][s], s == 0, fp.p("input_proj.net.0.weight"),
+                             x2, zs, coef[0][s], coef[1][s], coef[2][s], s == 0, fp.p("input_proj.net.0.weight"),
                              fp.p("input_proj.net.0.bias"), st["xh16"])
             return
         if not st["fused"]:
@@ -1198,12 +1228,12 @@ class DenoiserEngine:
         if st["fused"]:
             # LayerNorm -> fc -> update of x -> input_proj of the updated x for the next step, one pass over lout
             ops.sampler_tail(prec, lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), fp.p("fc.weight"), fp.p("fc.bias"),
-                             x2, st["z"][s], coef[0][s], coef[1][s], coef[2][s], s == 0, fp.p("input_proj.net.0.weight"),
+                             x2, zs, coef[0][s], coef[1][s], coef[2][s], s == 0, fp.p("input_proj.net.0.weight"),
                              fp.p("input_proj.net.0.bias"), xh)
             return
         ops.layernorm_fwd(lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), ln, None)
         ops.linear_fwd(prec, ln, fp.p("fc.weight"), fp.p("fc.bias"), pred)
-        ops.sampler_update(x2, pred, st["z"][s], coef[0][s], coef[1][s], coef[2][s], s == 0)
+        ops.sampler_update(x2, pred, zs, coef[0][s], coef[1][s], coef[2][s], s == 0)
 
     # -- get_loss + backward ------------------------------------------------
     def loss_and_grads(self, x0, t, i_idx, noise, time_info, cond, alphas, loss_sum, global_numel=None):

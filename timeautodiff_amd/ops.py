@@ -583,6 +583,13 @@ def draw_batch(seed, counter, N, B, T, K, n_steps, idx=None, t=None, i=None, noi
           _stream())
 
 
+def sampler_noise(seed, counter, row0, rows, K, out):
+    """out [rows, K] float32 = the standard normals of rows row0 .. row0+rows of the global latent tensor at step
+    ``counter`` (tad_sampler_noise: a function of (seed, counter, global row, k) alone)."""
+    assert out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == rows * K
+    _call("tad_sampler_noise", int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), int(row0), int(rows), int(K), _ptr(out), _stream())
+
+
 def zero_(t):
     """t[...] = 0 for a contiguous tensor or a 2-D view with unit column stride (float32 / bfloat16 / int32)."""
     if t.numel() == 0:
