@@ -228,6 +228,16 @@ int64_t tad_rnn_packed_bytes(int prec, int64_t H, int G);
  * Either output may be NULL. */
 int tad_rnn_pack_weights(int prec, int64_t H, int G, const float* w_hh, void* packed_fwd, void* packed_bwd,
                          tad_stream_t stream);
+
+/* The same for up to 16 matrices of one shape (the layers and directions of a stack) in ONE launch: the images are
+ * rebuilt after every optimizer step (DIFF.py:325 / VAE.py:345 `optimizer.step()` changes weight_hh_*), and a launch
+ * per image was 2 % of a training step.  packed_fwd / packed_bwd of a job may be NULL. */
+typedef struct {
+  const float* w_hh;
+  void* packed_fwd;
+  void* packed_bwd;
+} tad_rnn_pack_job_t;
+int tad_rnn_pack_weights_multi(int prec, int64_t H, int G, int njobs, const tad_rnn_pack_job_t* jobs, tad_stream_t stream);
 /* Gate-interleaved image of the input-side parameters of nblk directions / heads:
  * w_ih [nblk*G*H, in_dim] (torch's gate-major rows, blocks back to back), b_ih and b_hh
  * [nblk*G*H] -> w_gl [nblk*4H, in_dim] with row blk*4H + 4u + s = row blk*G*H + s*H + u

@@ -36,6 +36,10 @@ class TnJob(C.Structure):
                 ("a0", _i64), ("na", _i64), ("gate_map", C.c_int32 * 6), ("A16", _p), ("lda", _i64)]
 
 
+class RnnPackJob(C.Structure):
+    _fields_ = [("w_hh", _p), ("packed_fwd", _p), ("packed_bwd", _p)]
+
+
 class PackW16Job(C.Structure):
     _fields_ = [("src", _p), ("ld_src", _i64), ("n", _i64), ("k", _i64), ("dst", _p), ("ld_dst", _i64),
                 ("transpose", C.c_int32), ("pad_", C.c_int32)]
@@ -62,6 +66,7 @@ PROTOTYPES = {
     "tad_rnn_pack_input": (_i, [_i, _i64, _i64, _i, _p, _p, _p, _p, _i, _i64, _p, _p]),
     "tad_rnn_packed_bytes": (_i64, [_i, _i64, _i]),
     "tad_rnn_pack_weights": (_i, [_i, _i64, _i, _p, _p, _p, _p]),
+    "tad_rnn_pack_weights_multi": (_i, [_i, _i64, _i, _i, C.POINTER(RnnPackJob), _p]),
     "tad_add_noise": (_i, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "tad_sampler_update": (_i, [_i64, _p, _p, _p, _f, _f, _f, _i, _p]),
     "tad_sampler_tail": (_i, [_i, _i64, _i, _i, _i, _p, _i64, _p, _p, _f, _p, _p, _p, _p, _f, _f, _f, _i, _p, _p, _p, _i64, _p]),

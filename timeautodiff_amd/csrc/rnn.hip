@@ -52,8 +52,7 @@ __device__ __forceinline__ uint32_t pk2(float a, float b) {
 
 // forward image : blocks [j][kk][g], B(k = u_in, n = unit 32j+c of gate g)  = W[(g*H + unit)*H + u_in]
 // backward image: blocks [j][kk],    B(k = g*width + u, n = u_in = 32j+c)    = W[(g*H + u)*H + u_in]
-__global__ void pack_kernel(PackArgs a) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_elem(const PackArgs& a, int64_t gid) {
   const int lane = gid & 63;
   int64_t blk = gid >> 6;
   const int ks = a.bf16 ? 16 : 8;
@@ -87,6 +86,7 @@ __global__ void pack_kernel(PackArgs a) {
   }
   a.out[gid] = o;
 }
+__global__ void pack_kernel(PackArgs a) { pack_elem(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
 
 // Forward image for the 16-row form (v_mfma_f32_16x16x32_bf16): blocks [j][kk][g][nb] of 64 uint4, lane l holds
 // B(k = 32 kk + 8 (l / 16) + e, n = unit 32 j + 16 nb + l % 16 of gate g), e = 0..7; zeros beyond H either way.
@@ -95,8 +95,7 @@ struct Pack16Args {
   uint4* out;
   int H, G, NJ, nk32;
 };
-__global__ void pack16_kernel(Pack16Args a) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack16_elem(const Pack16Args& a, int64_t gid) {
   const int lane = gid & 63;
   int64_t blk = gid >> 6;
   if (blk >= (int64_t)a.NJ * a.nk32 * a.G * 2) return;
@@ -113,6 +112,31 @@ __global__ void pack16_kernel(Pack16Args a) {
   uint4 o;
   o.x = pk2(v[0], v[1]); o.y = pk2(v[2], v[3]); o.z = pk2(v[4], v[5]); o.w = pk2(v[6], v[7]);
   a.out[gid] = o;
+}
+__global__ void pack16_kernel(Pack16Args a) { pack16_elem(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+
+// Every image of up to 16 recurrent weight matrices of one shape in ONE launch (blockIdx.y = matrix; the threads of a
+// matrix cover its forward image, then its backward image, then its 16-row-form image): a model's images are rebuilt
+// after every optimizer step, and two dozen launches of a few microseconds each were 2 % of a training step.
+constexpr int PACK_MAXJOBS = 16;
+struct PackMultiArgs {
+  const float* w[PACK_MAXJOBS];
+  uint4* fwd[PACK_MAXJOBS];
+  uint4* bwd[PACK_MAXJOBS];
+  int H, G, NJ, nkf, nkb, nk32, width, bf16;
+  int64_t nf, nb, n16;      // threads of the three images
+};
+__global__ void pack_multi_kernel(PackMultiArgs a) {
+  const int job = blockIdx.y;
+  for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < a.nf + a.nb + a.n16; gid += (int64_t)gridDim.x * blockDim.x) {
+    if (gid < a.nf) {
+      if (a.fwd[job]) pack_elem(PackArgs{a.w[job], a.fwd[job], a.H, a.G, a.NJ, a.nkf, a.width, a.bf16, 0}, gid);
+    } else if (gid < a.nf + a.nb) {
+      if (a.bwd[job]) pack_elem(PackArgs{a.w[job], a.bwd[job], a.H, a.G, a.NJ, a.nkb, a.width, a.bf16, 1}, gid - a.nf);
+    } else if (a.fwd[job]) {
+      pack16_elem(Pack16Args{a.w[job], a.fwd[job] + a.nf, a.H, a.G, a.NJ, a.nk32}, gid - a.nf - a.nb);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1089,6 +1113,28 @@ extern "C" int tad_rnn_pack_weights(int prec, int64_t H, int G, const float* w_h
     hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, (hipStream_t)stream, a);
     TAD_LAUNCH_CHECK();
   }
+  return TAD_OK;
+}
+
+extern "C" int tad_rnn_pack_weights_multi(int prec, int64_t H, int G, int njobs, const tad_rnn_pack_job_t* jobs, tad_stream_t stream) {
+  TAD_CHECK(prec == TAD_F32 || prec == TAD_BF16, "tad_rnn_pack_weights_multi: bad prec %d", prec);
+  TAD_CHECK(H > 0 && H <= 1024 && (G == 3 || G == 4) && jobs && njobs >= 1 && njobs <= PACK_MAXJOBS, "tad_rnn_pack_weights_multi: bad arguments H=%ld G=%d njobs=%d (1..%d)",
+            (long)H, G, njobs, PACK_MAXJOBS);
+  const Geom g = geom(prec, H, G);
+  PackMultiArgs a{};
+  for (int k = 0; k < njobs; ++k) {
+    TAD_CHECK(jobs[k].w_hh, "tad_rnn_pack_weights_multi: job %d: null w_hh", k);
+    a.w[k] = jobs[k].w_hh;
+    a.fwd[k] = reinterpret_cast<uint4*>(jobs[k].packed_fwd);
+    a.bwd[k] = reinterpret_cast<uint4*>(jobs[k].packed_bwd);
+  }
+  a.H = (int)H; a.G = G; a.NJ = g.NJ; a.nkf = g.nkf; a.nkb = g.nkb; a.nk32 = g.nk32; a.width = g.width; a.bf16 = prec == TAD_BF16;
+  a.nf = (int64_t)g.NJ * g.nkf * G * 64; a.nb = (int64_t)g.NJ * g.nkb * 64; a.n16 = (int64_t)g.NJ * g.nk32 * G * 2 * 64;
+  int64_t gx = cdiv64(a.nf + a.nb + a.n16, 256);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)gx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, a);
+  TAD_LAUNCH_CHECK();
+  tad_note_kernel("pack_multi_kernel");
   return TAD_OK;
 }
 

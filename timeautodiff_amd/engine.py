@@ -401,10 +401,10 @@ class RnnStack:
         if not (do_f or do_b):
             return
         fp, nd, GH = self.fp, self.ndir, self.G * self.H
+        ops.rnn_pack_weights_multi(self.prec, self.H, self.G,
+                                   [(fp.p(self.name("weight_hh", layer, d)), self.packed_f[layer][d] if do_f else None,
+                                     self.packed_b[layer][d] if do_b else None) for layer in range(self.L) for d in range(nd)])
         for layer in range(self.L):
-            for d in range(nd):
-                ops.rnn_pack_weights(self.prec, self.H, self.G, fp.p(self.name("weight_hh", layer, d)),
-                                     self.packed_f[layer][d] if do_f else None, self.packed_b[layer][d] if do_b else None)
             if do_f:
                 ops.rnn_pack_input(self.cell, self.H, fp.pgroup(self.name("weight_ih", layer, 0), nd * GH, self.in_l(layer)),
                                    fp.pgroup(self.name("bias_ih", layer, 0), 1, nd * GH).view(-1),

@@ -379,6 +379,17 @@ def rnn_pack_weights(prec, H, G, w_hh, packed_fwd, packed_bwd):
     _call("tad_rnn_pack_weights", prec, H, G, w_hh.data_ptr(), _ptr(packed_fwd), _ptr(packed_bwd), _stream())
 
 
+def rnn_pack_weights_multi(prec, H, G, jobs):
+    """jobs: list of (w_hh [G*H, H], packed_fwd or None, packed_bwd or None): every image in one launch per 16 jobs."""
+    for lo in range(0, len(jobs), 16):
+        part = jobs[lo:lo + 16]
+        arr = (_lib.RnnPackJob * len(part))()
+        for k, (w, pf, pb) in enumerate(part):
+            assert w.is_contiguous() and w.shape == (G * H, H), w.shape
+            arr[k].w_hh, arr[k].packed_fwd, arr[k].packed_bwd = w.data_ptr(), _ptr(pf), _ptr(pb)
+        _call("tad_rnn_pack_weights_multi", prec, H, G, len(part), arr, _stream())
+
+
 def _store_of(t):
     return BF16 if t.dtype == torch.bfloat16 else F32
 
