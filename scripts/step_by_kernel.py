@@ -32,5 +32,5 @@ for key, kern, e0, e1, cost in t.records:
     a[1] += e0.elapsed_time(e1) * 1e3
 tot = sum(v[1] for v in agg.values()) / 5
 print(f"B={B}: {sum(v[0] for v in agg.values()) // 5} launches, {tot:.0f} us of kernel time per step")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("TOP", "14"))]:
     print(f"  {v[0] // 5:3d} x {v[1] / v[0]:7.1f} us = {v[1] / 5:7.1f} us  {k[0]} {k[1]}")
