@@ -977,6 +977,24 @@ def test_draw_batch_vs_oracle(ops, dev, N, B, T, K):
         ops.draw_batch(seed, counter, B - 1, B, T, K, 100, idx=idx)             # fewer windows than the sample
 
 
+@pytest.mark.parametrize("rows,E,cards", [(5000, 128, [8]), (1024, 16, [2, 7, 1]), (3001, 100, [16, 3]), (2000, 128, [17]), (4000, 160, [4])])
+def test_embed_bwd_forms(ops, dev, rows, E, cards):
+    """Embedding-table gradients at sizes that take the register-accumulating kernel (card <= 16, E <= 128, 1024+ rows)
+    and at sizes that keep the LDS-atomic one, against a float64 scatter-add; codes outside [0, card) clamp like the
+    forward's."""
+    rng = np.random.default_rng(rows + E)
+    nd = len(cards)
+    x = np.stack([rng.integers(-1, c + 1, rows) for c in cards], 1).astype(np.float32)        # some codes out of range
+    off = list(np.cumsum([0] + cards[:-1]))
+    dout = rnd(rng, rows, nd * E)
+    dt = torch.zeros(sum(cards), E, device=dev)
+    ops.embed_bwd(D(x, dev), D(dout, dev), dt, off, cards, E)
+    gref = np.zeros((sum(cards), E), dtype=np.float64)
+    for d in range(nd):
+        np.add.at(gref, off[d] + np.clip(x[:, d].astype(int), 0, cards[d] - 1), dout[:, d * E:(d + 1) * E])
+    assert fu.rel_err(dt.cpu().numpy(), gref) < 1e-5
+
+
 @pytest.mark.parametrize("rows,K,row0", [(1, 1, 0), (1000, 6, 0), (777, 5, 12345), (4096 * 24, 6, 2 ** 33)])
 def test_sampler_noise_vs_oracle(ops, dev, rows, K, row0):
     """tad_sampler_noise against its numpy restatement (2e-6 absolute: log / sin / cos), and a slice of the rows equals

@@ -151,6 +151,56 @@ __global__ void embed_bwd_lds_kernel(int64_t rows, int nd, int E, const float* _
   }
 }
 
+// Small tables (card <= 16, E <= 128): the sums stay in registers.  A wave owns rows (stride = waves of the launch), a
+// lane two columns of E; the row's code is wave-uniform, so the add goes to the registers of that code through a uniform
+// branch -- no LDS atomics in the loop (a float add in LDS costs about four cycles per lane: 245 cycles per wave
+// instruction, which is what bounded embed_bwd_lds_kernel at 90 us for 98 304 rows x 128).  The waves of a workgroup
+// combine in LDS, one global atomic per table entry and workgroup.
+constexpr int EB_CARD = 16;
+__global__ __launch_bounds__(256) void embed_bwd_reg_kernel(int64_t rows, int nd, int E, const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ dout, int64_t ldo, float* __restrict__ dtables, DiscMeta m) {
+  __shared__ float part[4][EB_CARD * 128];
+  const int d = blockIdx.y;
+  const int card = m.card[d];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+  float acc[EB_CARD][2];
+#pragma unroll
+  for (int c = 0; c < EB_CARD; ++c) acc[c][0] = acc[c][1] = 0.f;
+  const bool q0 = lane < E, q1 = lane + 64 < E;
+  constexpr int U = 4;                                   // rows in flight per wave
+  for (int64_t r0 = gw; r0 < rows; r0 += (int64_t)U * nw) {
+    int code[U];
+    float v0[U], v1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + (int64_t)u * nw;
+      code[u] = -1; v0[u] = v1[u] = 0.f;
+      if (r < rows) {
+        int cd = (int)x[r * ldx + d];
+        code[u] = __builtin_amdgcn_readfirstlane(min(max(cd, 0), card - 1));
+        const float* dr = dout + r * ldo + (int64_t)d * E;
+        v0[u] = q0 ? dr[lane] : 0.f;
+        v1[u] = q1 ? dr[lane + 64] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int c = 0; c < EB_CARD; ++c)
+        if (code[u] == c) { acc[c][0] += v0[u]; acc[c][1] += v1[u]; }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < EB_CARD; ++c) { part[wave][c * 128 + lane] = acc[c][0]; part[wave][c * 128 + 64 + lane] = acc[c][1]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < card * 128; i += blockDim.x) {
+    const int c = i >> 7, q = i & 127;
+    const float v = part[0][i] + part[1][i] + part[2][i] + part[3][i];
+    if (q < E && v != 0.f) atomicAdd(&dtables[((int64_t)m.off[d] + c) * E + q], v);
+  }
+}
+
 __global__ void embed_bwd_direct_kernel(int64_t rows, int nd, int E, const float* __restrict__ x, int64_t ldx,
                                         const float* __restrict__ dout, int64_t ldo, float* __restrict__ dtables,
                                         DiscMeta m) {
@@ -863,7 +913,15 @@ extern "C" int tad_embed_bwd(int64_t rows, int n_disc, int E, const float* x, in
   int maxcard = 0;
   for (int d = 0; d < n_disc; ++d) maxcard = cards[d] > maxcard ? cards[d] : maxcard;
   const size_t lds = (size_t)maxcard * E * sizeof(float);
-  if (lds <= 48 * 1024) {
+  static const char* reg_env = getenv("TAD_EMBED_BWD_REG");      // experiments: 0 = always the LDS-atomic kernel
+  if (maxcard <= EB_CARD && E <= 128 && rows >= 1024 && !(reg_env && atoi(reg_env) == 0)) {
+    int64_t nb = cdiv64(rows, 4 * 16);                   // at least 16 rows per wave
+    static const char* cap_env = getenv("TAD_EMBED_BWD_WGS");
+    const int64_t cap = cap_env && atoi(cap_env) > 0 ? atoi(cap_env) : 512;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL(embed_bwd_reg_kernel, dim3((unsigned)nb, (unsigned)n_disc), dim3(256), 0, EW_STREAM, rows, n_disc, E, x, ldx, dout, ldo,
+                       dtables, m);
+  } else if (lds <= 48 * 1024) {
     int64_t nb = cdiv64(rows, 256);
     if (nb > 512) nb = 512;
     const int64_t rpb = cdiv64(rows, nb);
