@@ -37,7 +37,8 @@ typedef void* tad_stream_t;
 enum { TAD_OK = 0, TAD_ERR_INVALID = 1, TAD_ERR_LAUNCH = 2 };
 enum { TAD_F32 = 0, TAD_BF16 = 1 };
 enum { TAD_ACT_NONE = 0, TAD_ACT_RELU = 1, TAD_ACT_SILU = 2 /* tad_mm16_nt only */,
-       TAD_ACT_DSILU = 3 /* tad_mm16_nt only: the result is multiplied by silu'(relu_of) instead of being masked by it */ };
+       TAD_ACT_DSILU = 3 /* tad_mm16_nt only: the result is multiplied by silu'(relu_of) instead of being masked by it */,
+       TAD_ACT_SILU_Z32 = 4 /* tad_mm16_nt only: TAD_ACT_SILU whose pre-activation output Z holds float32 (what SiLU's backward reads) */ };
 enum { TAD_CELL_LSTM = 0, TAD_CELL_GRU = 1 };
 
 int tad_abi_version(void);
@@ -104,7 +105,8 @@ int tad_linear_bwd_weight_b16(int64_t M, int64_t N, int64_t K, const void* dY16,
  * image: allocated (readable) for N rounded up to a multiple of 64 rows and K rounded up to a multiple of 128
  * columns (ldw >= that), zeros in columns K.. of every row; rows N.. may hold anything.  bias fp32 [N] or NULL.  residual / relu_of: [M,N] operands of dtype res_dtype / relu_dtype (TAD_F32 or TAD_BF16) or NULL; residual
  * may alias C.  C: fp32 or bf16 (c_dtype), ldc a multiple of 4.  Z16 (optional, bf16 [M,N]): receives the value
- * before `act` (the pre-activation a SiLU's backward needs, DIFF.py:58 / VAE.py:81).  act: NONE, RELU or SILU.
+ * before `act` (the pre-activation a SiLU's backward needs, DIFF.py:58 / VAE.py:81; float32 [M,N] with act =
+ * SILU_Z32).  act: NONE, RELU, SILU, SILU_Z32, or DSILU (the result times silu'(relu_of): a SiLU's backward).
  * With W16 = the transposed weight image this is also the input gradient dX = dY W. */
 int tad_mm16_nt(int64_t M, int64_t N, int64_t K, const void* A16, int64_t lda, const void* W16, int64_t ldw,
                 const float* bias, const void* residual, int res_dtype, int64_t ld_res, const void* relu_of,

@@ -39,7 +39,7 @@ def _nt(ops, dev, M, N, K, c16, act=0, res=None, relu=None, bias=True):
     U = torch.randn(M, N, device=dev, generator=g) if relu else None
     if relu == "bf16":
         U = U.bfloat16()
-    Z = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16) if act == 2 else None
+    Z = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16 if act == 2 else torch.float32) if act in (2, 4) else None
     ops.mm16_nt(A, Wp, b, C, act=act, residual=R, relu_of=U, z_out=Z)
     torch.cuda.synchronize()
     ref = A.double() @ W.double().T
@@ -50,7 +50,7 @@ def _nt(ops, dev, M, N, K, c16, act=0, res=None, relu=None, bias=True):
     zref = ref.clone()
     if act == 1:
         ref = ref.clamp_min(0)
-    elif act == 2:
+    elif act in (2, 4):
         ref = ref * torch.sigmoid(ref)
     if U is not None and act == 3:
         sg = torch.sigmoid(U.double())
@@ -60,7 +60,7 @@ def _nt(ops, dev, M, N, K, c16, act=0, res=None, relu=None, bias=True):
     assert not torch.isnan(C.float()).any()
     assert _rel(C, ref) < (4e-3 if c16 else 1e-5)
     if Z is not None:
-        assert _rel(Z, zref) < 4e-3
+        assert _rel(Z, zref) < (4e-3 if act == 2 else 1e-5)
 
 
 NT_SHAPES = [(5, 8, 8), (130, 72, 40), (257, 200, 208), (1000, 1600, 400), (300, 128, 448), (64, 432, 432), (77, 200, 800),
@@ -79,6 +79,7 @@ def test_mm16_nt_fused_epilogues(ops, dev, M, N, K):
     _nt(ops, dev, M, N, K, True, act=1, res="f32", relu="bf16")
     _nt(ops, dev, M, N, K, False, act=2, res="bf16", relu="f32")
     _nt(ops, dev, M, N, K, True, act=2)
+    _nt(ops, dev, M, N, K, True, act=4)                               # SiLU with float32 pre-activations beside the bf16 result
     _nt(ops, dev, M, N, K, True, act=3, relu="f32", bias=False)      # the backward of a SiLU as the product's epilogue
     _nt(ops, dev, M, N, K, False, act=3, relu="f32", bias=False)
 

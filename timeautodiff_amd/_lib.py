@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAD_HIP_LIB") or os.path.join(_HERE, "libtad_hip.so")   # override: A/B builds of the same ABI
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_SILU, ACT_DSILU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_DSILU, ACT_SILU_Z32 = 0, 1, 2, 3, 4
 CELL_LSTM, CELL_GRU = 0, 1
 
 _p = C.c_void_p

@@ -98,7 +98,7 @@ struct NtParams {
   const bf16_t* A; int64_t lda;
   const bf16_t* W; int64_t ldw;
   void* C; int64_t ldc; int c16;
-  bf16_t* Z; int64_t ldz;                  // optional: pre-activation values (before `act`), bf16
+  void* Z; int64_t ldz; int z32;           // optional: pre-activation values (before `act`), bf16 (fp32 with act = SILU_Z32)
   const float* bias;
   const void* res; int64_t ld_res; int res16;
   const void* relu; int64_t ld_relu; int relu16;
@@ -235,12 +235,12 @@ __global__ __launch_bounds__(64 * NT_NW, KS16 <= 36 ? 2 : 1) void mm16_nt_kernel
   constexpr uint32_t OOB = 0xfffffff0u;
   const uint32_t esz = p.c16 ? 2u : 4u;
   const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
-  const __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc(p.Z, 0, (int)(uint32_t)(p.Z ? p.M * p.ldz * 2 : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc(p.Z, 0, (int)(uint32_t)(p.Z ? p.M * p.ldz * (p.z32 ? 4 : 2) : 0), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)(uint32_t)(p.res ? p.M * p.ld_res * (p.res16 ? 2 : 4) : 0), 0x00020000);
   const __amdgpu_buffer_rsrc_t u_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.relu), 0, (int)(uint32_t)(p.relu ? p.M * p.ld_relu * (p.relu16 ? 2 : 4) : 0), 0x00020000);
   // byte offsets of this lane's row
   const int64_t rowc = row_ok ? row : 0;
-  const uint32_t c_row = (uint32_t)(rowc * p.ldc) * esz, z_row = (uint32_t)(rowc * p.ldz) * 2u;
+  const uint32_t c_row = (uint32_t)(rowc * p.ldc) * esz, z_row = (uint32_t)(rowc * p.ldz) * (p.z32 ? 4u : 2u);
   const uint32_t r_row = (uint32_t)(rowc * p.ld_res) * (p.res16 ? 2u : 4u), u_row = (uint32_t)(rowc * p.ld_relu) * (p.relu16 ? 2u : 4u);
 
   // 4 consecutive values of a bf16 (e16) or fp32 [M,N] operand at byte offset off (zeros outside the operand)
@@ -359,11 +359,15 @@ __global__ __launch_bounds__(64 * NT_NW, KS16 <= 36 ? 2 : 1) void mm16_nt_kernel
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += m[j];
           }
-          if (p.Z) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])}, z_rs, nok ? z_row + (uint32_t)n * 2u : OOB, 0, 0);
+          if (p.Z) {
+            if (p.z32) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                                              z_rs, nok ? z_row + (uint32_t)n * 4u : OOB, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])}, z_rs, nok ? z_row + (uint32_t)n * 2u : OOB, 0, 0);
+          }
           if (p.act == TAD_ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-          } else if (p.act == TAD_ACT_SILU) {
+          } else if (p.act == TAD_ACT_SILU || p.act == TAD_ACT_SILU_Z32) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoid_acc(v[j]);
           }
@@ -707,10 +711,11 @@ extern "C" int tad_mm16_nt(int64_t M, int64_t N, int64_t K, const void* A16, int
   // every [M,N] operand moves in 16-byte pieces: bf16 ones need 8-element, fp32 ones 4-element aligned rows
   auto mn_ok = [&](const void* q, int64_t ld, int dt) { return al16(q) && ld >= N && ld % (dt == TAD_BF16 ? 8 : 4) == 0 && (dt == TAD_BF16 || dt == TAD_F32); };
   TAD_CHECK(mn_ok(C, ldc, c_dtype), "tad_mm16_nt: C needs a 16-byte aligned base and ldc %% 8 == 0 (bf16) / %% 4 == 0 (fp32)");
-  TAD_CHECK(!Z16 || mn_ok(Z16, ldz, TAD_BF16), "tad_mm16_nt: bad Z16");
+  TAD_CHECK(!Z16 || mn_ok(Z16, ldz, act == TAD_ACT_SILU_Z32 ? TAD_F32 : TAD_BF16), "tad_mm16_nt: bad Z16");
   TAD_CHECK(!residual || mn_ok(residual, ld_res, res_dtype), "tad_mm16_nt: bad residual");
   TAD_CHECK(!relu_of || mn_ok(relu_of, ld_relu, relu_dtype), "tad_mm16_nt: bad relu_of");
-  TAD_CHECK(act == TAD_ACT_NONE || act == TAD_ACT_RELU || act == TAD_ACT_SILU || (act == TAD_ACT_DSILU && relu_of), "tad_mm16_nt: bad act %d (TAD_ACT_DSILU needs relu_of)", act);
+  TAD_CHECK(act == TAD_ACT_NONE || act == TAD_ACT_RELU || act == TAD_ACT_SILU || (act == TAD_ACT_DSILU && relu_of) || (act == TAD_ACT_SILU_Z32 && Z16),
+            "tad_mm16_nt: bad act %d (TAD_ACT_DSILU needs relu_of, TAD_ACT_SILU_Z32 needs Z)", act);
   TAD_CHECK(lda < (1 << 22) && ldw < (1 << 22) && ldc < (1 << 22) && N * ldw < (1ll << 30), "tad_mm16_nt: leading dimension too large");
   // the [M,N] operands are addressed with 32-bit byte offsets
   TAD_CHECK(M * ldc * 4 < 0xfff00000ll && M * ld_res * 4 < 0xfff00000ll && M * ld_relu * 4 < 0xfff00000ll && M * ldz * 2 < 0xfff00000ll,
@@ -721,7 +726,7 @@ extern "C" int tad_mm16_nt(int64_t M, int64_t N, int64_t K, const void* A16, int
   p.A = reinterpret_cast<const bf16_t*>(A16); p.lda = lda;
   p.W = reinterpret_cast<const bf16_t*>(W16); p.ldw = ldw;
   p.C = C; p.ldc = ldc; p.c16 = c_dtype == TAD_BF16;
-  p.Z = reinterpret_cast<bf16_t*>(Z16); p.ldz = ldz;
+  p.Z = Z16; p.ldz = ldz; p.z32 = act == TAD_ACT_SILU_Z32;
   p.bias = bias;
   p.res = residual; p.ld_res = ld_res; p.res16 = res_dtype == TAD_BF16;
   p.relu = relu_of; p.ld_relu = ld_relu; p.relu16 = relu_dtype == TAD_BF16;

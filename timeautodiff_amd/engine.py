@@ -8,7 +8,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
-from .ops import ACT_DSILU, ACT_RELU, BF16, CELL_GRU, CELL_LSTM, F32
+from .ops import ACT_DSILU, ACT_RELU, ACT_SILU_Z32, BF16, CELL_GRU, CELL_LSTM, F32
 
 ALIGN = 64  # floats (256 B)
 # TAD_GRAD_STREAM=1 moves the launches nothing waits for before the optimizer step (weight gradients, table gradients,
@@ -682,8 +682,9 @@ class EmbBlock:
             z1 = ws.get(f"{tag}.z1", (rows, 16 * nn))
             a1 = ws.get(f"{tag}.a1_16", (rows, 16 * nn), dtype=b16)
             ops.sincos_features(x[:, nd:nd + nn], feats)
-            ops.mm16_nt(feats, im["n0"]["fwd"], fp.p(pre + "mlp_nums.0.bias"), z1)
-            ops.silu_fwd(z1, a1)
+            # z1 (float32: SiLU's backward reads it) and a1 = silu(z1) (bfloat16: the next product's operand) leave the
+            # same launch
+            ops.mm16_nt(feats, im["n0"]["fwd"], fp.p(pre + "mlp_nums.0.bias"), a1, act=ACT_SILU_Z32, z_out=z1)
             ops.mm16_nt(a1, im["n2"]["fwd"], fp.p(pre + "mlp_nums.2.bias"), ecat[:, nd * E:])
         w2 = fp.p(pre + "mlp_output.2.weight")
         if self.last16:

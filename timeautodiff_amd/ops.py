@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ACT_DSILU, BF16, CELL_GRU, CELL_LSTM, F32, RnnBwdDir, RnnDir  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ACT_DSILU, ACT_SILU_Z32, BF16, CELL_GRU, CELL_LSTM, F32, RnnBwdDir, RnnDir  # noqa: F401
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -285,13 +285,13 @@ def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=
         udt = _dt(relu_of)
         assert Mu == M and Nu == N
     if z_out is not None:
-        zp, Mz, Nz, ldz = as2d(z_out, torch.bfloat16)
+        zp, Mz, Nz, ldz = as2d(z_out, torch.float32 if act == ACT_SILU_Z32 else torch.bfloat16)
         assert Mz == M and Nz == N
     _call("tad_mm16_nt", M, N, K, ap, lda, wp, ldw, _ptr(bias), rp or None, rdt, ldr, up or None, udt, ldu, cp, _dt(c), ldc,
           zp or None, ldz, act, _stream(),
           cost=(2.0 * M * N * K, 2.0 * (M * K + N * K) + c.element_size() * M * N
                 + (residual.element_size() * M * N if residual is not None else 0)
-                + (relu_of.element_size() * M * N if relu_of is not None else 0) + (2.0 * M * N if z_out is not None else 0)))
+                + (relu_of.element_size() * M * N if relu_of is not None else 0) + (z_out.element_size() * M * N if z_out is not None else 0)))
 
 
 TN_MAXJOBS = 12
