@@ -168,6 +168,16 @@ int tad_colsum(int64_t M, int64_t N, const float* dY, int64_t ldy, const float* 
                int64_t row_scale_stride, float scale_mul, float* out_sum, float* out_sum2, float* out_wsum,
                tad_stream_t stream);
 
+/* Gradients of the linear halves of the two positional encodings (reference DIFF.py: PositionalEncoding.linear_proj of
+ * t_enc and i_enc, whose outputs are columns [col1, col1+L) and [col2, col2+L) of the input of proj, weight W [N, ldw]
+ * fp32) from g16 = the bf16-stored gradient of proj's pre-activations [M, N]: gb += W[:, col..]^T sum_r g[r],
+ * gw += mul * W[:, col..]^T sum_r s[r] g[r], s1 / s2 the per-row scalars the encodings were evaluated at.  Equal to
+ * the column sums of g W[:, col..] without forming that product.  round_w != 0: W is rounded to bf16 first (the operand
+ * of the bf16 mode).  sums: 3 N floats of workspace.  N a multiple of 8, at most 512; ldg a multiple of 8. */
+int tad_enc_grad_b16(int64_t M, int N, const void* g16, int64_t ldg, const float* s1, int64_t s1_stride, const float* s2,
+                     int64_t s2_stride, const float* W, int64_t ldw, int col1, int col2, int L, float mul1, float mul2,
+                     int round_w, float* sums, float* gb1, float* gw1, float* gb2, float* gw2, tad_stream_t stream);
+
 /* ------------------------------------------------------------------ recurrent family
  * Per-direction arguments of the persistent LSTM / GRU sequence kernels.  xproj holds
  * the input-side pre-activations x_t W_ih^T (+ b_ih, and + b_hh for LSTM) for all

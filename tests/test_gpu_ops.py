@@ -500,6 +500,67 @@ def test_sincos_embed_posenc_silu(ops, dev):
     assert fu.rel_err(dz.cpu().numpy(), da * oops.silu_grad(zt.astype(np.float64))) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_feature_kernels_wide_and_narrow_forms(ops, dev, dtype):
+    """sincos / embedding lookup / positional encoding pick a form with 16-byte stores when the rows of the result are
+    aligned for it and an element-per-thread form otherwise: the two must agree bit for bit (same arithmetic)."""
+    rng = np.random.default_rng(11)
+    rows, nn_, nd, E, H = 1000, 27, 2, 64, 200
+    cards = [8, 3]
+    off = [0, 8]
+    x = np.concatenate([np.stack([rng.integers(0, c, rows) for c in cards], 1).astype(np.float32),
+                        rng.random((rows, nn_), dtype=np.float32)], 1)
+    xd = D(x, dev)
+    tables = D(rnd(rng, sum(cards), E), dev)
+
+    def both(width, call):
+        wide = torch.zeros(rows, width + 8, device=dev, dtype=dtype)         # row pitch a multiple of 16 bytes
+        narrow = torch.zeros(rows, width + 9, device=dev, dtype=dtype)       # odd pitch: rows are not 16-byte aligned
+        call(wide[:, :width]); call(narrow[:, :width])
+        assert torch.equal(wide[:, :width], narrow[:, :width])
+        assert not wide[:, width:].any() and not narrow[:, width:].any()
+        return wide[:, :width].float().cpu().numpy()
+
+    tol = 2e-6 if dtype == torch.float32 else 2.0 ** -8
+    sc = both(16 * nn_, lambda o: ops.sincos_features(xd[:, nd:], o))
+    assert np.max(np.abs(sc - oops.sincos_features(x[:, nd:]))) < tol
+    em = both(nd * E, lambda o: ops.embed_fwd(xd[:, :nd], tables, off, cards, E, o))
+    ref = np.concatenate([tables.cpu().numpy()[off[d] + x[:, d].astype(int)] for d in range(nd)], 1)
+    assert np.max(np.abs(em - ref)) <= (0 if dtype == torch.float32 else 2.0 ** -8 * np.abs(ref).max())
+    for mx, tv in ((1.0, rng.random(rows, dtype=np.float32)), (100.0, rng.integers(0, 100, rows).astype(np.float32))):
+        s_, sh = oops.posenc_tables(H, mx)
+        w, b = rnd(rng, H // 2, 1), rnd(rng, H // 2)
+        po = both(H, lambda o: ops.posenc_fwd(D(tv, dev), 1, rows, H, 1.0 / mx, D(w, dev), D(b, dev), D(s_, dev), D(sh, dev), o))
+        pref = oops.posenc_fwd(tv[:, None], w, b, mx, s_, sh)
+        assert np.max(np.abs(po - pref)) < (1e-5 if dtype == torch.float32 else 2.0 ** -8 * max(1.0, np.abs(pref).max()))
+
+
+@pytest.mark.parametrize("M,N,L", [(24 * 37, 200, 100), (5000, 64, 32), (333, 512, 256), (3, 24, 12)])
+def test_enc_grad_equals_column_sums_of_the_product(ops, dev, M, N, L):
+    """tad_enc_grad_b16 against the form it replaces, in float64 numpy: the product g W[:, cols] of the bf16-rounded
+    operands followed by its plain and row-weighted column sums (the model tests check the same gradients against the
+    oracle, which forms that product)."""
+    rng = np.random.default_rng(M + N)
+    g = torch.from_numpy(rnd(rng, M, N)).to(dev).to(torch.bfloat16)
+    W = rnd(rng, N, 4 * N)
+    s1 = rng.random(M, dtype=np.float32)
+    s2 = rng.integers(0, 100, M).astype(np.float32)
+    col1, col2, mul2 = N, 2 * N, 1.0 / 100.0
+    out = [torch.full((L,), 0.5, device=dev) for _ in range(4)]                 # gradients accumulate
+    sums = torch.full((3 * N,), 7.0, device=dev)                                 # workspace: cleared by the call
+    ops.enc_grad_b16(g, D(s1, dev), D(s2, dev), D(W, dev), col1, col2, L, 1.0, mul2, sums, *out)
+    g64 = g.float().cpu().numpy().astype(np.float64)
+    W16 = torch.from_numpy(W).to(torch.bfloat16).float().numpy().astype(np.float64)
+    ref = []
+    for col, s_, mul in ((col1, s1, 1.0), (col2, s2, mul2)):
+        d = g64 @ W16[:, col:col + L]
+        ref += [0.5 + d.sum(0), 0.5 + mul * (d * s_[:, None].astype(np.float64)).sum(0)]
+    for o, r in zip(out, ref):
+        assert fu.rel_err(o.cpu().numpy(), r) < 2e-5
+    sums_ref = np.concatenate([(g64 * s1[:, None]).sum(0), (g64 * s2[:, None]).sum(0), g64.sum(0)])
+    assert fu.rel_err(sums.cpu().numpy(), sums_ref) < 2e-5
+
+
 @pytest.mark.parametrize("Dn", [48, 400, 1024])
 def test_layernorm(ops, dev, Dn):
     rng = np.random.default_rng(Dn)

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "tad_cvt_bf16": (_i, [_i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p]),
     "tad_pack_w16": (_i, [_i, C.POINTER(PackW16Job), _p]),
     "tad_colsum": (_i, [_i64, _i64, _p, _i64, _p, _i64, _f, _p, _p, _p, _p]),
+    "tad_enc_grad_b16": (_i, [_i64, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p]),
     "tad_rnn_fwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p]),
     "tad_rnn_bwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnBwdDir), _p]),
     "tad_rnn_pack_input": (_i, [_i, _i64, _i64, _i, _p, _p, _p, _p, _i, _i64, _p, _p]),

@@ -18,6 +18,11 @@ inline unsigned ew_grid(int64_t n, int per_thread = 1) {
   return (unsigned)g;
 }
 
+// every row of a [rows, ld] tensor of `esz`-byte elements starts at a multiple of `align` bytes
+inline bool wide_rows_ok(const void* p, int64_t ld, int esz, int align) {
+  return (reinterpret_cast<uintptr_t>(p) % (uintptr_t)align) == 0 && (ld * esz) % align == 0;
+}
+
 // block-wide sum of one value per thread -> atomicAdd(out) once per block
 __device__ __forceinline__ void block_atomic_sum(float v, float* out) {
   __shared__ float part[EW_BLOCK / 64];
@@ -105,6 +110,41 @@ __global__ void sincos_kernel(int64_t rows, int nn, const float* __restrict__ x,
   }
 }
 
+// 8 consecutive results as one 16-byte (bf16) or two 16-byte (fp32) stores; dst is 16-byte aligned
+template <typename OT>
+__device__ __forceinline__ void store8(OT* dst, const float (&v)[8]) {
+  if constexpr (sizeof(OT) == 2) {
+    OT t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = (OT)v[k];
+    *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, t);
+  } else {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+// The same values, one thread per (row, numeric column): x is read once, the 8 sines and the 8 cosines of the column
+// leave as 16-byte stores (rows of `out` 16-byte aligned), and no thread loops -- the grid covers the elements, so
+// the load -> sincos -> store chains of a wave's threads are all in flight together.
+template <typename OT>
+__global__ void sincos8_kernel(int64_t rows, int nn, const float* __restrict__ x, int64_t ldx, OT* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * nn) return;
+  const int64_t r = e / nn;
+  const int j = (int)(e - r * nn);
+  const float pi = 3.14159265358979323846f;
+  const float xv = x[r * ldx + j];
+  float sn[8], cs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float freq = __fmul_rn((float)(1 << k), pi);
+    sincosf(__fmul_rn(freq, xv), &sn[k], &cs[k]);
+  }
+  store8(out + r * ldo + 8 * j, sn);
+  store8(out + r * ldo + 8 * (nn + j), cs);
+}
+
 struct DiscMeta {
   int32_t off[MAX_DISC];
   int32_t card[MAX_DISC];
@@ -122,6 +162,24 @@ __global__ void embed_fwd_kernel(int64_t rows, int nd, int E, const float* __res
     code = min(max(code, 0), m.card[d] - 1);
     out[r * ldo + c] = (OT)tables[((int64_t)m.off[d] + code) * E + q];
   }
+}
+
+// E a multiple of 8, rows of `out` 16-byte aligned: one thread per 8 consecutive entries of a table row
+template <typename OT>
+__global__ void embed_fwd8_kernel(int64_t rows, int nd, int E, const float* __restrict__ x, int64_t ldx,
+                                  const float* __restrict__ tables, DiscMeta m, OT* __restrict__ out, int64_t ldo) {
+  const int e8 = E / 8;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * nd * e8) return;
+  const int64_t r = e / (nd * e8);
+  const int c = (int)(e - r * (nd * e8));
+  const int d = c / e8, q = 8 * (c - d * e8);
+  int code = (int)x[r * ldx + d];
+  code = min(max(code, 0), m.card[d] - 1);
+  const float* src = tables + ((int64_t)m.off[d] + code) * E + q;
+  const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  store8(out + r * ldo + (int64_t)d * E + q, v);
 }
 
 // One workgroup = one discrete column and one slab of rows; the column's table gradient is
@@ -232,6 +290,44 @@ __global__ void posenc_kernel(int64_t rows, int H, const float* __restrict__ t, 
     if (c < L) v = __fadd_rn(__fmul_rn(__fmul_rn(tv, inv_max), w[c]), b[c]);
     else v = sinf(__fadd_rn(__fmul_rn(tv, scale[c - L]), shift[c - L]));
     out[r * ldo + c] = (OT)v;
+  }
+}
+
+// H a multiple of 8, rows of `out` 8-byte (bf16) or 16-byte (fp32) aligned: one thread per 4 columns, same arithmetic
+// per element, no loop.  blockIdx.y picks the half of the row (0: the linear columns, 1: the sines), so a wave never
+// holds both kinds: with them mixed every wave pays for the sine of all its lanes.
+template <typename OT>
+__global__ void posenc4_kernel(int64_t rows, int H, const float* __restrict__ t, int64_t ts, float inv_max,
+                               const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
+                               const float* __restrict__ shift, OT* __restrict__ out, int64_t ldo) {
+  const int L = H / 2, l4 = L / 4;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * l4) return;
+  const int64_t r = e / l4;
+  const int c = 4 * (int)(e - r * l4);
+  const float tv = t[r * ts];
+  float v[4];
+  // the four per-column tables are 16-byte aligned (checked at the launch): one load per table and thread
+  if (blockIdx.y == 0) {
+    const float tn = __fmul_rn(tv, inv_max);
+    const float4 wv = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
+    const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __fadd_rn(__fmul_rn(tn, ws[k]), bs[k]);
+  } else {
+    const float4 sv = *reinterpret_cast<const float4*>(scale + c), hv = *reinterpret_cast<const float4*>(shift + c);
+    const float ss[4] = {sv.x, sv.y, sv.z, sv.w}, hs[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = sinf(__fadd_rn(__fmul_rn(tv, ss[k]), hs[k]));
+  }
+  OT* dst = out + r * ldo + c + (blockIdx.y ? L : 0);
+  if constexpr (sizeof(OT) == 2) {
+    OT q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = (OT)v[k];
+    *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, q);
+  } else {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -740,6 +836,96 @@ __global__ void colsum_kernel(int64_t M, int64_t N, const float* __restrict__ dY
   }
 }
 
+// Column sums of a bf16 matrix, plain and weighted by two per-row scalars, 8 columns per lane (16-byte loads):
+// U[0][c] += sum_r s1[r] A[r,c];  U[1][c] += sum_r s2[r] A[r,c];  U[2][c] += sum_r A[r,c].
+// LPR lanes (a power of two >= N / 8) serve one row, a wave 64 / LPR rows at a time, four row groups in flight; the
+// rows of a wave meet through lane shuffles, the waves of a workgroup in LDS, the workgroups in 3 N global atomics.
+template <int LPR>
+__global__ __launch_bounds__(256) void wcolsum16_kernel(int64_t M, int N, const bf16_t* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ s1, int64_t st1, const float* __restrict__ s2,
+                                                        int64_t st2, float* __restrict__ U) {
+  extern __shared__ float wc_part[];                     // [4 waves][3][N]
+  constexpr int RPW = 64 / LPR, UN = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, c = 8 * (lane % LPR);
+  const bool cok = c < N;
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+  float a0[8], a1[8], a2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a0[k] = a1[k] = a2[k] = 0.f;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * RPW + sub; r0 < M; r0 += UN * stride) {
+    uint4 v[UN];
+    float w1[UN], w2[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t r = r0 + u * stride;
+      const bool ok = r < M;
+      v[u] = (ok && cok) ? *reinterpret_cast<const uint4*>(A + r * lda + c) : make_uint4(0u, 0u, 0u, 0u);
+      w1[u] = ok ? s1[r * st1] : 0.f;
+      w2[u] = ok ? s2[r * st2] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const uint32_t q[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = __uint_as_float(q[k] << 16), hi = __uint_as_float(q[k] & 0xffff0000u);
+        a0[2 * k] += lo; a0[2 * k + 1] += hi;
+        a1[2 * k] = fmaf(w1[u], lo, a1[2 * k]); a1[2 * k + 1] = fmaf(w1[u], hi, a1[2 * k + 1]);
+        a2[2 * k] = fmaf(w2[u], lo, a2[2 * k]); a2[2 * k + 1] = fmaf(w2[u], hi, a2[2 * k + 1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) {
+      a0[k] += __shfl_xor(a0[k], m); a1[k] += __shfl_xor(a1[k], m); a2[k] += __shfl_xor(a2[k], m);
+    }
+  }
+  if (sub == 0 && cok) {
+    float* pw = wc_part + (size_t)wave * 3 * N;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pw[c + k] = a1[k]; pw[N + c + k] = a2[k]; pw[2 * N + c + k] = a0[k]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * N; i += 256) {
+    const float t = wc_part[i] + wc_part[3 * N + i] + wc_part[6 * N + i] + wc_part[9 * N + i];
+    if (t != 0.f) atomicAdd(&U[i], t);
+  }
+}
+
+// Gradients of two Linear(1 -> L) maps whose outputs are columns [col1, col1 + L) and [col2, col2 + L) of the input of a
+// Linear with weight W [N, ldw]: with g the gradient of that Linear's pre-activations, the bias gradient is
+// W[:, col..]^T (sum_r g[r]) and the weight gradient W[:, col..]^T (sum_r s[r] g[r]) -- U holds those three row sums.
+// blockIdx.x: the map; blockIdx.y: 8 rows of W (their loads are in flight together); one thread per output column.
+__global__ void enc_grad_finish_kernel(int N, int L, const float* __restrict__ W, int64_t ldw, int col1, int col2,
+                                       const float* __restrict__ U, float mul1, float mul2, int round16, float* __restrict__ gb1,
+                                       float* __restrict__ gw1, float* __restrict__ gb2, float* __restrict__ gw2) {
+  const int which = blockIdx.x, o0 = 8 * blockIdx.y;
+  const int col = which ? col2 : col1;
+  float* gb = which ? gb2 : gb1;
+  float* gw = which ? gw2 : gw1;
+  const float mul = which ? mul2 : mul1;
+  float us[8], uw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { us[k] = U[2 * N + o0 + k]; uw[k] = U[which * N + o0 + k]; }
+  for (int c = threadIdx.x; c < L; c += blockDim.x) {
+    float wv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wv[k] = W[(int64_t)(o0 + k) * ldw + col + c];
+    float ab = 0.f, aw = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = round16 ? (float)(bf16_t)wv[k] : wv[k];      // the operand the product form of this gradient multiplies by
+      ab = fmaf(w, us[k], ab);
+      aw = fmaf(w, uw[k], aw);
+    }
+    atomicAdd(&gb[c], ab);
+    atomicAdd(&gw[c], aw * mul);
+  }
+}
+
 }  // namespace
 
 #define EW_STREAM ((hipStream_t)stream)
@@ -848,7 +1034,13 @@ extern "C" int tad_grad_norm_sq(int64_t n, const float* g, float* out_sum, tad_s
 static int sincos_features(int64_t rows, int n_nums, const float* x, int64_t ldx, void* out, int out_dtype, int64_t ldo, tad_stream_t stream) {
   TAD_CHECK(rows >= 0 && n_nums > 0 && x && out && ldx >= n_nums && ldo >= 16 * n_nums, "tad_sincos_features: bad arguments");
   if (rows == 0) return TAD_OK;
-  if (out_dtype == TAD_BF16)
+  const int64_t n8 = rows * n_nums;
+  const bool wide = wide_rows_ok(out, ldo, out_dtype == TAD_BF16 ? 2 : 4, 16) && cdiv64(n8, EW_BLOCK) < ((int64_t)1 << 31);
+  if (wide && out_dtype == TAD_BF16)
+    hipLaunchKernelGGL(sincos8_kernel<bf16_t>, dim3((unsigned)cdiv64(n8, EW_BLOCK)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_nums, x, ldx, (bf16_t*)out, ldo);
+  else if (wide)
+    hipLaunchKernelGGL(sincos8_kernel<float>, dim3((unsigned)cdiv64(n8, EW_BLOCK)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_nums, x, ldx, (float*)out, ldo);
+  else if (out_dtype == TAD_BF16)
     hipLaunchKernelGGL(sincos_kernel<bf16_t>, dim3(ew_grid(rows * n_nums * 8)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_nums, x, ldx, (bf16_t*)out, ldo);
   else
     hipLaunchKernelGGL(sincos_kernel<float>, dim3(ew_grid(rows * n_nums * 8)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_nums, x, ldx, (float*)out, ldo);
@@ -886,7 +1078,16 @@ static int embed_fwd(int64_t rows, int n_disc, int E, const float* x, int64_t ld
   DiscMeta m{};
   if (int rc = fill_meta(m, n_disc, tab_off, cards, "tad_embed_fwd")) return rc;
   if (rows == 0) return TAD_OK;
-  if (out_dtype == TAD_BF16)
+  const int64_t n8 = rows * n_disc * (E / 8);
+  const bool wide = E % 8 == 0 && (reinterpret_cast<uintptr_t>(tables) & 15) == 0 && wide_rows_ok(out, ldo, out_dtype == TAD_BF16 ? 2 : 4, 16) &&
+                    cdiv64(n8, EW_BLOCK) < ((int64_t)1 << 31);
+  if (wide && out_dtype == TAD_BF16)
+    hipLaunchKernelGGL(embed_fwd8_kernel<bf16_t>, dim3((unsigned)cdiv64(n8, EW_BLOCK)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_disc, E, x, ldx,
+                       tables, m, (bf16_t*)out, ldo);
+  else if (wide)
+    hipLaunchKernelGGL(embed_fwd8_kernel<float>, dim3((unsigned)cdiv64(n8, EW_BLOCK)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_disc, E, x, ldx,
+                       tables, m, (float*)out, ldo);
+  else if (out_dtype == TAD_BF16)
     hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(ew_grid(rows * n_disc * E)), dim3(EW_BLOCK), 0, EW_STREAM, rows, n_disc, E, x, ldx,
                        tables, m, (bf16_t*)out, ldo);
   else
@@ -941,7 +1142,13 @@ static int posenc_fwd(int64_t rows, int H, const float* t, int64_t t_stride, flo
                       const float* b, const float* scale, const float* shift, OT* out, int64_t ldo, tad_stream_t stream) {
   TAD_CHECK(rows >= 0 && H >= 2 && t && w && b && scale && shift && out && ldo >= H, "tad_posenc_fwd: bad arguments");
   if (rows == 0) return TAD_OK;
-  if (rows * H + (int64_t)4096 * EW_BLOCK < ((int64_t)1 << 32))       // the grid-stride counter must not wrap either
+  const int64_t n4 = rows * (H / 8);
+  const bool tables16 = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(scale) |
+                          reinterpret_cast<uintptr_t>(shift)) & 15) == 0;
+  if (H % 8 == 0 && tables16 && wide_rows_ok(out, ldo, (int)sizeof(OT), 4 * (int)sizeof(OT)) && cdiv64(n4, EW_BLOCK) < ((int64_t)1 << 31))
+    hipLaunchKernelGGL((posenc4_kernel<OT>), dim3((unsigned)cdiv64(n4, EW_BLOCK), 2), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max,
+                       w, b, scale, shift, out, ldo);
+  else if (rows * H + (int64_t)4096 * EW_BLOCK < ((int64_t)1 << 32))       // the grid-stride counter must not wrap either
     hipLaunchKernelGGL((posenc_kernel<uint32_t, OT>), dim3(ew_grid(rows * H)), dim3(EW_BLOCK), 0, EW_STREAM, rows, H, t, t_stride, inv_max,
                        w, b, scale, shift, out, ldo);
   else
@@ -1120,6 +1327,34 @@ extern "C" int tad_adam_step_dev(int64_t n, float* p, const float* g, float* m, 
   if (n == 0) return TAD_OK;
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, p, g, m, v, beta1, beta2, eps, weight_decay,
                      0.f, 0.f, coef2);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_enc_grad_b16(int64_t M, int N, const void* g16, int64_t ldg, const float* s1, int64_t s1_stride, const float* s2,
+                                int64_t s2_stride, const float* W, int64_t ldw, int col1, int col2, int L, float mul1, float mul2,
+                                int round_w, float* sums, float* gb1, float* gw1, float* gb2, float* gw2, tad_stream_t stream) {
+  TAD_CHECK(M >= 0 && N > 0 && N % 8 == 0 && N <= 512 && g16 && ldg >= N && ldg % 8 == 0 && s1 && s2 && W && sums && gb1 && gw1 && gb2 && gw2,
+            "tad_enc_grad_b16: bad arguments (N a multiple of 8, at most 512; ldg a multiple of 8)");
+  TAD_CHECK((reinterpret_cast<uintptr_t>(g16) & 15) == 0, "tad_enc_grad_b16: g16 must be 16-byte aligned");
+  TAD_CHECK(L > 0 && col1 >= 0 && col2 >= 0 && col1 + L <= ldw && col2 + L <= ldw, "tad_enc_grad_b16: column ranges outside W");
+  if (M == 0) return TAD_OK;
+  if (hipMemsetAsync(sums, 0, (size_t)3 * N * sizeof(float), EW_STREAM) != hipSuccess) { tad_set_error("tad_enc_grad_b16: memset failed"); return TAD_ERR_LAUNCH; }
+  const int lpr = N <= 64 ? 8 : N <= 128 ? 16 : N <= 256 ? 32 : 64;
+  const int rpw = 64 / lpr;
+  int64_t wgs = cdiv64(M, (int64_t)4 * rpw * 4);          // at least four row groups per wave
+  if (wgs > 512) wgs = 512;
+  const size_t lds = (size_t)4 * 3 * N * sizeof(float);
+  const bf16_t* g = (const bf16_t*)g16;
+  switch (lpr) {
+    case 8: hipLaunchKernelGGL(wcolsum16_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, EW_STREAM, M, N, g, ldg, s1, s1_stride, s2, s2_stride, sums); break;
+    case 16: hipLaunchKernelGGL(wcolsum16_kernel<16>, dim3((unsigned)wgs), dim3(256), lds, EW_STREAM, M, N, g, ldg, s1, s1_stride, s2, s2_stride, sums); break;
+    case 32: hipLaunchKernelGGL(wcolsum16_kernel<32>, dim3((unsigned)wgs), dim3(256), lds, EW_STREAM, M, N, g, ldg, s1, s1_stride, s2, s2_stride, sums); break;
+    default: hipLaunchKernelGGL(wcolsum16_kernel<64>, dim3((unsigned)wgs), dim3(256), lds, EW_STREAM, M, N, g, ldg, s1, s1_stride, s2, s2_stride, sums); break;
+  }
+  TAD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(enc_grad_finish_kernel, dim3(2, (unsigned)(N / 8)), dim3(128), 0, EW_STREAM, N, L, W, ldw, col1, col2, sums, mul1, mul2,
+                     round_w, gb1, gw1, gb2, gw2);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

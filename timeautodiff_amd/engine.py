@@ -1027,16 +1027,16 @@ class DenoiserEngine:
         wt = im["proj"]["tr"]
         dxh = ws.get("dxh16", (BT, H), dtype=b16)
         ops.mm16_nt(dpz, img_rows(wt, 0, H), None, dxh)
-        denc = ws.get("denc", (BT, 2 * H))
-        ops.mm16_nt(dpz, img_rows(wt, H, 2 * H), None, denc)
         dtenc = ws.get("dtenc16", (BT, H), dtype=b16)
         ops.mm16_nt(dpz, img_rows(wt, 3 * H, H), None, dtenc)
         gx = ws.get("gx16", (BT, 2 * H + im["coin"]["widths"][1]), dtype=b16)
         fp.queue_tn(dxh, dict(b=gx[:, 2 * H:], c=fp.g("input_proj.net.0.weight"), db=fp.g("input_proj.net.0.bias")))
-        fp.defer(ops.colsum, denc[:, :Lh], out_sum=fp.g("t_enc.linear_proj.bias"), row_scale=t1, scale_mul=1.0,
-                 out_wsum=fp.g("t_enc.linear_proj.weight"))
-        fp.defer(ops.colsum, denc[:, H:H + Lh], out_sum=fp.g("i_enc.linear_proj.bias"), row_scale=i1, scale_mul=1.0 / self.i_max,
-                 out_wsum=fp.g("i_enc.linear_proj.weight"))
+        # the t / step encodings have parameters in their linear halves only, and d(cat) of those columns is needed
+        # only summed over the rows (plain: bias, weighted by t / i: weight): three weighted column sums of dpz times
+        # proj's weight columns, instead of a [BT, 2H] product and its column sums
+        fp.defer(ops.enc_grad_b16, dpz, t1, i1, fp.p("proj.net.0.weight"), H, 2 * H, Lh, 1.0, 1.0 / self.i_max,
+                 ws.get("enc_sums", (3 * H,)), fp.g("t_enc.linear_proj.bias"), fp.g("t_enc.linear_proj.weight").view(-1),
+                 fp.g("i_enc.linear_proj.bias"), fp.g("i_enc.linear_proj.weight").view(-1))
         if self.on_first_bucket is not None:
             fp.flush_tn()                   # proj's weight gradient is among the queued products: it belongs to this bucket
             self.on_first_bucket()          # gradients of input_proj .. fc (the head of the flat buffer) are all enqueued

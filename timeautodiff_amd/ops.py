@@ -363,6 +363,19 @@ def pack_w16(jobs):
     _call("tad_pack_w16", len(jobs), arr, _stream())
 
 
+def enc_grad_b16(g16, s1, s2, W, col1, col2, L, mul1, mul2, sums, gb1, gw1, gb2, gw2, round_w=True):
+    """Bias / weight gradients of two Linear(1 -> L) maps feeding columns col1.. / col2.. of a Linear with weight W, from
+    the bf16 gradient g16 of that Linear's pre-activations and the per-row scalars s1 / s2 (see tad_enc_grad_b16)."""
+    gp, M, N, ldg = as2d(g16, torch.bfloat16)
+    assert W.dim() == 2 and W.shape[0] == N and W.stride(1) == 1 and W.dtype == torch.float32
+    assert s1.numel() == M and s2.numel() == M and s1.is_contiguous() and s2.is_contiguous()
+    assert sums.numel() >= 3 * N and sums.is_contiguous() and sums.dtype == torch.float32
+    for t in (gb1, gw1, gb2, gw2):
+        assert t.numel() == L and t.is_contiguous() and t.dtype == torch.float32
+    _call("tad_enc_grad_b16", M, N, gp, ldg, _ptr(s1), 1, _ptr(s2), 1, _ptr(W), W.stride(0), col1, col2, L, float(mul1), float(mul2),
+          1 if round_w else 0, _ptr(sums), _ptr(gb1), _ptr(gw1), _ptr(gb2), _ptr(gw2), _stream())
+
+
 def colsum(dy, out_sum=None, out_sum2=None, row_scale=None, row_scale_stride=1, scale_mul=1.0, out_wsum=None):
     dyp, M, N, ldy = as2d(dy)
     _call("tad_colsum", M, N, dyp, ldy, _ptr(row_scale), row_scale_stride, float(scale_mul), _ptr(out_sum), _ptr(out_sum2),
