@@ -1249,6 +1249,7 @@ extern "C" int tad_ln_fc_fwd(int prec, int64_t rows, int D, int K, const float* 
   const int r16 = prec == TAD_BF16 ? 1 : 0;
 #define LNFC(NC) hipLaunchKernelGGL((ln_fc_fwd_kernel<NC, 8>), dim3((unsigned)g), dim3(EW_BLOCK), 0, EW_STREAM, rows, D, K, r16, x, ldx, gamma, beta, eps, fc_w, fc_b, y, ldy, mean_rstd, pred)
   if (D <= 128) LNFC(2);
+  else if (D > 384 && D <= 448) LNFC(7);      // 2H = 400 of the bench: 7 columns per lane, not 8
   else LNFC(8);
 #undef LNFC
   TAD_LAUNCH_CHECK();
@@ -1271,6 +1272,7 @@ extern "C" int tad_ln_fc_bwd(int prec, int64_t rows, int D, int K, const float* 
   const int r16 = prec == TAD_BF16 ? 1 : 0;
 #define LNFC(NC, DWV, G, NAV) hipLaunchKernelGGL((ln_fc_bwd_kernel<NC, 8, DWV>), dim3((unsigned)(G)), dim3(EW_BLOCK), sizeof(float) * (NAV) * NC * 64, EW_STREAM, rows, D, K, r16, dpred, x, ldx, gamma, beta, mean_rstd, fc_w, dx, lddx, dgamma, dbeta, dfc_w, dfc_b)
   if (D <= 128) { LNFC(2, false, g, 2); LNFC(2, true, g2, 8); }
+  else if (D > 384 && D <= 448) { LNFC(7, false, g, 2); LNFC(7, true, g2, 8); }
   else { LNFC(8, false, g, 2); LNFC(8, true, g2, 8); }
 #undef LNFC
   TAD_LAUNCH_CHECK();
