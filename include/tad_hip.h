@@ -87,6 +87,8 @@ int tad_linear_bwd_weight(int prec, int64_t M, int64_t N, int64_t K, const float
  * operands need 16-byte aligned rows, leading dimensions and extents that are multiples of 8.
  *   fwd_b16:        Y = act(X W16^T + bias), X fp32, W16 bf16 [N,K], Y fp32 or bf16 (y_dtype);
  *   bwd_data_b16:   dX = dY16 W16 (+ dX) with the ReLU mask, dY16 bf16 [M,N], W16 bf16 [N,K], dX fp32;
+ *   bwd_data_b16o:  the same product with a bf16 result dX16 and a bf16 mask operand (no accumulate): for a dX
+ *                   that only matrix products read (dX16, relu_of16: 16-byte aligned, ld multiples of 4);
  *   bwd_weight_b16: dW += dY16^T X' with db/db2, T/tshift and gate_map as above; the bias
  *                   sums are taken over the bf16 values of dY16. */
 int tad_linear_fwd_b16(int64_t M, int64_t N, int64_t K, const float* X, int64_t ldx, const void* W16, int64_t ldw,
@@ -94,6 +96,9 @@ int tad_linear_fwd_b16(int64_t M, int64_t N, int64_t K, const float* X, int64_t 
 int tad_linear_bwd_data_b16(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const void* W16,
                             int64_t ldw, float* dX, int64_t ldx, const float* relu_of, int64_t ld_relu,
                             int accumulate, tad_stream_t stream);
+int tad_linear_bwd_data_b16o(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const void* W16,
+                             int64_t ldw, void* dX16, int64_t ldx, const void* relu_of16, int64_t ld_relu,
+                             tad_stream_t stream);
 int tad_linear_bwd_weight_b16(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const float* X,
                               int64_t ldx, float* dW, int64_t ldw, float* db, float* db2, int64_t T,
                               int64_t tshift, const int32_t* gate_map, tad_stream_t stream);

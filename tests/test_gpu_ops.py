@@ -535,6 +535,31 @@ def test_feature_kernels_wide_and_narrow_forms(ops, dev, dtype):
         assert np.max(np.abs(po - pref)) < (1e-5 if dtype == torch.float32 else 2.0 ** -8 * max(1.0, np.abs(pref).max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(24 * 41, 1600, 200), (700, 800, 128), (5, 64, 72), (4096, 600, 200)])
+def test_linear_bwd_data_bf16_result(ops, dev, M, N, K):
+    """tad_linear_bwd_data_b16o (bf16 result, bf16 mask operand, written by the product's epilogue) against the float32
+    result of tad_linear_bwd_data_b16 rounded and masked by tad_cvt_bf16: the same accumulators, bit for bit."""
+    rng = np.random.default_rng(M + K)
+    dY16 = torch.from_numpy(rnd(rng, M, N)).bfloat16().to(dev)
+    W16 = torch.from_numpy(rnd(rng, N, K)).bfloat16().to(dev)
+    mask = torch.from_numpy(rnd(rng, M, K)).bfloat16().to(dev)
+    mask[::3, ::5] = 0                                                  # zeros and negative zeros mask like negatives
+    mask[1::3, 1::5] = -0.0
+    for m in (None, mask):
+        dX = torch.zeros(M, K, device=dev)
+        ops.linear_bwd_data_b16(dY16, W16, dX)
+        want = torch.full((M, K + 8), 3.0, dtype=torch.bfloat16, device=dev)
+        ops.cvt_bf16(dX, want[:, :K], relu_of=m)
+        got = torch.full((M, K + 8), 3.0, dtype=torch.bfloat16, device=dev)
+        ops.linear_bwd_data_b16o(dY16, W16, got[:, :K], relu_of16=m)
+        assert torch.equal(got, want)
+        ref = dY16.float().cpu().numpy().astype(np.float64) @ W16.float().cpu().numpy().astype(np.float64)
+        if m is not None:
+            ref = ref * (m.float().cpu().numpy() > 0)
+        g = got[:, :K].float().cpu().numpy()
+        assert np.all(np.abs(g - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-5 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("M,N,L", [(24 * 37, 200, 100), (5000, 64, 32), (333, 512, 256), (3, 24, 12)])
 def test_enc_grad_equals_column_sums_of_the_product(ops, dev, M, N, L):
     """tad_enc_grad_b16 against the form it replaces, in float64 numpy: the product g W[:, cols] of the bf16-rounded

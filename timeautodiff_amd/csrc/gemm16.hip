@@ -50,6 +50,27 @@ extern "C" int tad_linear_bwd_data_b16(int64_t M, int64_t N, int64_t K, const vo
   return launch_bf16<KC16, RC16>(pick_cfg(TAD_BF16, M, K, MIN_WGS), p, 1, (hipStream_t)stream);
 }
 
+extern "C" int tad_linear_bwd_data_b16o(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const void* W16,
+                                        int64_t ldw, void* dX16, int64_t ldx, const void* relu_of16, int64_t ld_relu,
+                                        tad_stream_t stream) {
+  TAD_CHECK(M >= 0 && N > 0 && K > 0 && ldy >= N && ldw >= K && ldx >= K, "tad_linear_bwd_data_b16o: bad shape M=%ld N=%ld K=%ld",
+            (long)M, (long)N, (long)K);
+  TAD_CHECK(dY16 && W16 && dX16, "tad_linear_bwd_data_b16o: null pointer");
+  TAD_CHECK(ldy < LD_MAX && ldw < LD_MAX && ldx < LD_MAX && ld_relu < LD_MAX, "tad_linear_bwd_data_b16o: leading dimension too large");
+  TAD_CHECK(!relu_of16 || ld_relu >= K, "tad_linear_bwd_data_b16o: bad ld_relu");
+  TAD_CHECK(rows16(dY16, ldy) && N % 8 == 0, "tad_linear_bwd_data_b16o: dY16 needs 16-byte aligned rows (ldy %% 8 == 0) and N %% 8 == 0");
+  TAD_CHECK(rows16(W16, ldw) && K % 8 == 0, "tad_linear_bwd_data_b16o: W16 needs 16-byte aligned rows (ldw %% 8 == 0) and K %% 8 == 0");
+  if (M == 0) return TAD_OK;
+  GemmParams p{};
+  p.A = dY16; p.sa_row = ldy; p.sa_k = 1;
+  p.B = W16; p.sb_row = 1; p.sb_k = ldw;
+  p.C = dX16; p.ldc = ldx; p.c16 = 1; p.M = M; p.N = K; p.K = N;
+  p.relu_of = reinterpret_cast<const float*>(relu_of16); p.ld_relu = ld_relu; p.relu16 = 1;
+  p.k_per_split = cdiv64(N, BK) * BK;
+  TAD_CHECK(wide_epilogue_ok(p), "tad_linear_bwd_data_b16o: dX16 and relu_of16 need 16-byte aligned bases and leading dimensions that are multiples of 4");
+  return launch_bf16<KC16, RC16>(pick_cfg(TAD_BF16, M, K, MIN_WGS), p, 1, (hipStream_t)stream);
+}
+
 extern "C" int tad_linear_bwd_weight_b16(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const float* X,
                                          int64_t ldx, float* dW, int64_t ldw, float* db, float* db2, int64_t T,
                                          int64_t tshift, const int32_t* gate_map, tad_stream_t stream) {

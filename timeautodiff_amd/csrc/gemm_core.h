@@ -59,6 +59,7 @@ struct GemmParams {
   int64_t M, N, K;
   const float* bias; const float* bias2;
   const float* relu_of; int64_t ld_relu;
+  int relu16;                // relu_of points to bf16 values (wide epilogue only)
   const float* residual; int64_t ld_res;
   float* rowsum; float* rowsum2;   // += sum_k A(i,k) (bias gradients; added by the first column tile)
   int act, atomic;
@@ -497,7 +498,7 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[TM][TN], const
   const int64_t mrem64 = p.M - ib, nrem64 = p.N - jb;
   const int mrem = (int)(mrem64 < 32 * TM ? mrem64 : 32 * TM), nrem = (int)(nrem64 < 32 * TN ? nrem64 : 32 * TN);
   float* cbase = reinterpret_cast<float*>(p.C) + ib * p.ldc + jb;           // fp32 C
-  bf16_t* cbase16 = reinterpret_cast<bf16_t*>(p.C) + ib * p.ldc + jb;       // bf16 C (p.c16; MODE 0 only)
+  bf16_t* cbase16 = reinterpret_cast<bf16_t*>(p.C) + ib * p.ldc + jb;       // bf16 C (p.c16)
   const uint32_t ldc = (uint32_t)p.ldc;
   const bool has_res = p.residual != nullptr, has_relu = p.relu_of != nullptr;
   const float* rbase = has_res ? p.residual + ib * p.ld_res + jb : cbase;
@@ -525,13 +526,20 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[TM][TN], const
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       float4 res[8], rel[8];
       if constexpr (MODE == 1) {
+        // an absent operand is not read: its stand-in address (C) is a float32 one only when C is float32
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
           const int rowl = 32 * it + 4 * ps;
           const bool ok = cok && rowl + rrow < mrem;
           const uint32_t urow = rowl < mrem ? (uint32_t)rowl : 0u, ucol = 64 * jp < nrem ? 64u * jp : 0u;
-          res[ps] = *reinterpret_cast<const float4*>((rbase + (urow * ldr + ucol)) + (ok ? voff_r : 0u));
-          rel[ps] = *reinterpret_cast<const float4*>((ubase + (urow * ldu + ucol)) + (ok ? voff_u : 0u));
+          res[ps] = rel[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (has_res) res[ps] = *reinterpret_cast<const float4*>((rbase + (urow * ldr + ucol)) + (ok ? voff_r : 0u));
+          if (has_relu && p.relu16) {
+            const uint2 t = *reinterpret_cast<const uint2*>((reinterpret_cast<const bf16_t*>(p.relu_of) + ib * p.ld_relu + jb + (urow * ldu + ucol)) + (ok ? voff_u : 0u));
+            rel[ps] = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+          } else if (has_relu) {
+            rel[ps] = *reinterpret_cast<const float4*>((ubase + (urow * ldu + ucol)) + (ok ? voff_u : 0u));
+          }
         }
       }
 #pragma unroll
@@ -552,13 +560,11 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[TM][TN], const
             if (!(rel[ps].w > 0.f)) v.w = 0.f;
           }
         }
-        if constexpr (MODE == 0) {
-          if (p.c16) {
-            uint2 u;
-            u.x = pack_bf16x2(v.x, v.y); u.y = pack_bf16x2(v.z, v.w);
-            if (ok) *reinterpret_cast<uint2*>((cbase16 + ((uint32_t)rowl * ldc + 64u * jp)) + voff) = u;
-            continue;
-          }
+        if (p.c16) {
+          uint2 u;
+          u.x = pack_bf16x2(v.x, v.y); u.y = pack_bf16x2(v.z, v.w);
+          if (ok) *reinterpret_cast<uint2*>((cbase16 + ((uint32_t)rowl * ldc + 64u * jp)) + voff) = u;
+          continue;
         }
         if (ok) *reinterpret_cast<float4*>((cbase + ((uint32_t)rowl * ldc + 64u * jp)) + voff) = v;
       }

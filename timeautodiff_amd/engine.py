@@ -539,7 +539,10 @@ class RnnStack:
                                       fp.g(self.name("weight_ih", layer, d)), db=gb_ih[sl], db2=gb_hh[sl] if lstm else None,
                                       gate_map=in_map)
 
-    def backward(self, dout, ws: Workspace, tag, need_dx, relu_of=None):
+    def backward(self, dout, ws: Workspace, tag, need_dx, relu_of=None, dx16=None):
+        """BPTT through the stack; returns the gradient wrt the stack's input (None unless need_dx).
+        dx16: a bfloat16 [B*T, in] buffer for that gradient when only matrix products read it (relu_of is then a
+        bfloat16 mask operand): the product writes it directly where its operands are bf16-stored."""
         fp, H, G, nd, prec = self.fp, self.H, self.G, self.ndir, self.prec
         B, T = self._B, self._T
         BT = B * T
@@ -579,12 +582,18 @@ class RnnStack:
             # gradient wrt the layer input (the unused slot of a GRU meets a zero row of the weight image)
             if layer > 0 or need_dx:
                 padded = shared and self.in_p(layer) != in_l
+                wl = self.w_gl[layer][:, :self.in_p(layer)]
+                if layer == 0 and dx16 is not None and sdt == torch.bfloat16 and shared and not padded:
+                    ops.linear_bwd_data_b16o(dg, wl, dx16, relu_of16=relu_of)
+                    dout = dx16
+                    continue
                 dx = ws.get(f"{tag}.dx{layer}", (BT, (self.in_p(layer) if padded else in_l) if shared else nd * H))
+                if layer == 0 and dx16 is not None:
+                    relu_of, mask16 = None, relu_of            # the mask is applied with the rounding below
                 ro = relu_of if layer == 0 else None
                 assert not (padded and ro is not None), "a ReLU mask on a padded layer input is not supported"
                 bwd_data = (lambda dy, w, o, r=None: ops.linear_bwd_data_b16(dy, w, o, relu_of=r)) if sdt == torch.bfloat16 else \
                     (lambda dy, w, o, r=None: ops.linear_bwd_data(prec, dy, w, o, relu_of=r))
-                wl = self.w_gl[layer][:, :self.in_p(layer)]
                 if shared:
                     bwd_data(dg, wl, dx, ro)
                 else:
@@ -592,6 +601,9 @@ class RnnStack:
                         sl = slice(d * H4, (d + 1) * H4)
                         bwd_data(dg[:, sl], wl[sl], dx[:, d * H:(d + 1) * H])
                 dout = dx[:, :in_l] if padded else dx            # the pad columns meet zero weights: they hold zeros
+                if layer == 0 and dx16 is not None:
+                    ops.cvt_bf16(dout, dx16, relu_of=mask16)
+                    dout = dx16
             else:
                 dout = None
         return dout
@@ -1017,9 +1029,8 @@ class DenoiserEngine:
         lout = ws.get("lstm.out%d" % (self.L - 1), (BT, 2 * H))
         gout16 = self.gru.out16[self.L - 1]
         dlout = self._ln_fc_bwd(dpred, lout, BT)
-        dpa = self.lstm.backward(dlout, ws, "lstm", need_dx=True)
         dpz = ws.get("dpz16", (BT, H), dtype=b16)
-        ops.cvt_bf16(dpa, dpz, relu_of=pa)                                  # the ReLU of proj
+        self.lstm.backward(dlout, ws, "lstm", need_dx=True, relu_of=pa, dx16=dpz)      # includes the ReLU of proj
         fp.queue_tn(dpz, dict(b=cat, c=fp.g("proj.net.0.weight"), db=fp.g("proj.net.0.bias")))
         # d(cat) in three pieces of proj's transposed image: the input-projection / cond_output share and the
         # time-encoding share feed matrix products only (bf16); the t / step encodings' share is summed column by
@@ -1051,7 +1062,7 @@ class DenoiserEngine:
         dgout = ws.get("dgout", (BT, 2 * H))
         ops.mm16_nt(dxh, im["co"]["tr"], None, dgout)
         fp.queue_tn(dxh, dict(b=gout16, c=fp.g("cond_output.weight"), db=fp.g("cond_output.bias")))
-        demb = self.gru.backward(dgout, ws, "gru", need_dx=True)
+        demb = self.gru.backward(dgout, ws, "gru", need_dx=True, dx16=ws.get("demb16", (BT, self.gru.in_l(0)), dtype=b16))
         self.emb.backward(demb, ws, "emb")
         fp.join()
 

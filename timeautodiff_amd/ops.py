@@ -250,6 +250,21 @@ def linear_bwd_data_b16(dy16, w16, dx, relu_of=None, accumulate=False):
           cost=(2.0 * M * N * K, 2.0 * (M * N + N * K) + 4.0 * M * K * (1 + bool(rp) + bool(accumulate))))
 
 
+def linear_bwd_data_b16o(dy16, w16, dx16, relu_of16=None):
+    """dx16 = dy16 w16, masked where relu_of16 <= 0: every operand bfloat16 (a dx that only matrix products read)."""
+    b16 = torch.bfloat16
+    dyp, M, N, ldy = as2d(dy16, b16)
+    wp, Nw, K, ldw = as2d(w16, b16)
+    dxp, Mx, Kx, ldx = as2d(dx16, b16)
+    assert N == Nw and M == Mx and K == Kx, (dy16.shape, w16.shape, dx16.shape)
+    rp, ldr = None, 0
+    if relu_of16 is not None:
+        rp, Mr, Kr, ldr = as2d(relu_of16, b16)
+        assert Mr == M and Kr == K
+    _call("tad_linear_bwd_data_b16o", M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, _stream(),
+          cost=(2.0 * M * N * K, 2.0 * (M * N + N * K) + 2.0 * M * K * (1 + bool(rp))))
+
+
 def _dt(t):
     return BF16 if t.dtype == torch.bfloat16 else F32
 
