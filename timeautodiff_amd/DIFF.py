@@ -218,9 +218,10 @@ class DiffusionTrainer:
                  process_group=None, draws="reference", dev=None, graph=None):
         model.set_compute_dtype(dtype)
         # graph=True: everything of a step after the draws (gathers, add_noise, forward, loss, backward on both streams,
-        # Adam) is captured once as a HIP graph and replayed -- one launch per step for the host instead of a hundred,
-        # which is what a step costs at the reference's batch of 100 windows.  Default: on for batches of at most 512
-        # windows in a single process, where the step is bound by launch latency; TAD_TRAIN_GRAPH=0/1 overrides.
+        # Adam) is captured once as a HIP graph and replayed -- one launch per step for the host instead of some
+        # sixty.  Default: off.  With the step's launches as few and as cheap for the host as they are now, the device
+        # is the bound even at the reference's batch of 100 windows, and the replay measures 0-4 % slower than the
+        # launches one by one at 100 / 256 / 512 windows (scripts/graph_vs_eager.py); TAD_TRAIN_GRAPH=0/1 overrides.
         self._graph_opt = graph
         self._graph = None
         self.model = model
@@ -294,7 +295,7 @@ class DiffusionTrainer:
             return bool(self._graph_opt)
         if env is not None:
             return env == "1"
-        return self.B <= 512
+        return False
 
     @ops.device_scope(lambda self, *a, **k: self.eng.device)
     def step(self, draw=None, loss_out=None):
@@ -404,8 +405,8 @@ def train_diffusion(latent_features, cond_df, data_dict, hidden_dim, num_layers,
     the reference.  Keyword-only extras: batch_size (default = diffusion_steps, the reference's
     hard-coded choice), lr (Adam default 1e-3), dtype ('fp32' | 'bf16'), process_group (data
     parallel over RCCL), draws ('reference' | 'device'), losses (a list that receives the
-    per-iteration losses, fetched once at the end), graph (replay each step as one captured HIP graph; default: on
-    for batches of at most 512 windows in a single process)."""
+    per-iteration losses, fetched once at the end), graph (replay each step as one captured HIP graph; default: off,
+    the launches one by one measure as fast or faster)."""
     emb_dim = 128
     info = data_dict["parser"].datatype_info()
     n_bins, n_cats, n_nums, cards = info["n_bins"], info["n_cats"], info["n_nums"], info["cards"]
