@@ -784,7 +784,12 @@ extern "C" int tad_mm16_tn(int64_t M, int64_t T, const void* A16, int64_t lda, i
   const int64_t target = wgs_env ? atoi(wgs_env) : 256;
   const int64_t slabs = cdiv64(M, TN_BK);
   int64_t splits = target / tiles;
-  if (splits > slabs) splits = slabs;
+  // a split shorter than a dozen slabs is all pipeline fill and atomics: at 2400 rows (the reference's batch of 100
+  // windows) the five launches of a step average 48.7 / 41.0 / 37.4 / 40.0 us with at least 4 / 8 / 12 / 16 slabs per
+  // split (6144 rows: 59 / 59 / 59 / 57); from 256 * 12 slabs per tile column on (the bench) the limit does not bind
+  static const char* ms_env = getenv("TAD_MM16_TN_MINSLABS");
+  const int64_t min_slabs = ms_env && atoi(ms_env) > 0 ? atoi(ms_env) : 12;
+  if (splits > slabs / min_slabs) splits = slabs / min_slabs;
   if (splits < 1) splits = 1;
   p.rows_per_split = cdiv64(slabs, splits) * TN_BK;
   p.nsplits = (int)cdiv64(M, p.rows_per_split);
