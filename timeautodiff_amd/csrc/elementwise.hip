@@ -1265,7 +1265,13 @@ extern "C" int tad_ln_fc_bwd(int prec, int64_t rows, int D, int K, const float* 
   if (rows == 0) return TAD_OK;
   static const char* cap_env = getenv("TAD_LNFC_BWD_GRID");     // experiments: workgroups of the two launches
   static const char* cap2_env = getenv("TAD_LNFC_DW_GRID");
-  int64_t g = cdiv64(rows, EW_BLOCK / 64), g2 = g;
+  // every workgroup ends with 2 D (first launch) or K D (second) atomics onto the same addresses: at least 4 rows per
+  // wave in both (2400 rows x 400, the pair: 48 us at 1 / 1 rows per wave, 36 at 1 / 4, 29.5 at 2 / 4 and 4 / 8,
+  // 27 at 4 / 4, 32 at 8 / 8); the caps below bind from 24 576 / 12 288 rows on
+  static const char* rpw_env = getenv("TAD_LNFC_RPW");          // experiments: "a,b" = rows per wave of the two launches
+  int rpw1 = 4, rpw2 = 4;
+  if (rpw_env) sscanf(rpw_env, "%d,%d", &rpw1, &rpw2);
+  int64_t g = cdiv64(rows, (int64_t)rpw1 * (EW_BLOCK / 64)), g2 = cdiv64(rows, (int64_t)rpw2 * (EW_BLOCK / 64));
   const int64_t cap = cap_env ? atoi(cap_env) : 1536, cap2 = cap2_env ? atoi(cap2_env) : 768;     // measured at 98 304 x 400: 246 us; (1536, 256) 390, (1024, 1024) 316
   if (g > cap) g = cap;
   if (g2 > cap2) g2 = cap2;
