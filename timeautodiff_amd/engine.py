@@ -833,10 +833,17 @@ class DenoiserEngine:
             self.im = dict(co=self.imgs.add(p_("cond_output.weight"), fwd=False, tr=True),
                            coin=self.imgs.add_side_by_side([p_("cond_output.weight"), p_("input_proj.net.0.weight")],
                                                            [p_("cond_output.bias"), p_("input_proj.net.0.bias")]),
-                           proj=self.imgs.add(p_("proj.net.0.weight"), fwd=True, tr=True),
+                           proj=self.imgs.add(p_("proj.net.0.weight"), fwd=True, tr=False),
                            te2=self.imgs.add(p_("time_encode.2.weight"), fwd=True, tr=True))
             if self.time_dim % 8 == 0:
                 self.im["te0"] = self.imgs.add(p_("time_encode.0.weight"), fwd=True, tr=False)
+            # d(cat) is needed for the first and the last H columns of cat only (input projection / cond_output share,
+            # time-encoding share): their rows of proj's transposed weight, one below the other, make one product
+            Hh, wp = self.H, p_("proj.net.0.weight")
+            tr2 = self.imgs.alloc(2 * Hh, Hh, device)
+            self.imgs.items.append((wp[:, :Hh], tr2[:Hh], True))
+            self.imgs.items.append((wp[:, 3 * Hh:], tr2[Hh:2 * Hh], True))
+            self.im["proj"]["tr2"] = tr2
             # the sampler's per-step share of `proj`: its first H input columns (the input projection of x)
             self.im["proj_x"] = self.imgs.add(p_("proj.net.0.weight")[:, :self.H], fwd=True, tr=False)
         self.ws = Workspace(device)
@@ -1032,14 +1039,12 @@ class DenoiserEngine:
         dpz = ws.get("dpz16", (BT, H), dtype=b16)
         self.lstm.backward(dlout, ws, "lstm", need_dx=True, relu_of=pa, dx16=dpz)      # includes the ReLU of proj
         fp.queue_tn(dpz, dict(b=cat, c=fp.g("proj.net.0.weight"), db=fp.g("proj.net.0.bias")))
-        # d(cat) in three pieces of proj's transposed image: the input-projection / cond_output share and the
-        # time-encoding share feed matrix products only (bf16); the t / step encodings' share is summed column by
-        # column (their weight and bias gradients): float32
-        wt = im["proj"]["tr"]
-        dxh = ws.get("dxh16", (BT, H), dtype=b16)
-        ops.mm16_nt(dpz, img_rows(wt, 0, H), None, dxh)
-        dtenc = ws.get("dtenc16", (BT, H), dtype=b16)
-        ops.mm16_nt(dpz, img_rows(wt, 3 * H, H), None, dtenc)
+        # d(cat): the input-projection / cond_output share and the time-encoding share (first and last H columns) feed
+        # matrix products only: one bf16 product over their rows of proj's transposed weight; the t / step encodings'
+        # share is needed summed over the rows only (enc_grad_b16 below)
+        dxt = ws.get("dxt16", (BT, 2 * H), dtype=b16)
+        ops.mm16_nt(dpz, im["proj"]["tr2"], None, dxt)
+        dxh, dtenc = dxt[:, :H], dxt[:, H:]
         gx = ws.get("gx16", (BT, 2 * H + im["coin"]["widths"][1]), dtype=b16)
         fp.queue_tn(dxh, dict(b=gx[:, 2 * H:], c=fp.g("input_proj.net.0.weight"), db=fp.g("input_proj.net.0.bias")))
         # the t / step encodings have parameters in their linear halves only, and d(cat) of those columns is needed
