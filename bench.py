@@ -155,12 +155,13 @@ def trace_step(step_fn, ms_step, ops, fp=None, peak_flops=PEAK_BF16, NTR=3):
     by_kernel = tr.summary_by_kernel()
     kstat = {}
     for kern, calls in by_kernel.items():
-        ent = kstat.setdefault(kern, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-        for key, (cnt, ms, fl, by) in calls.items():
+        ent = kstat.setdefault(kern, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0, issued=0.0))
+        for key, (cnt, ms, fl, by, iss) in calls.items():
             ent["calls"] += cnt
             ent["ms"] += ms
-            ent["flops"] += fl * cnt
+            ent["flops"] += fl * cnt            # fl, by, iss: means over the calls of the key, each call with its own cost
             ent["bytes"] += by * cnt
+            ent["issued"] += iss * cnt
     dom = max(kstat, key=lambda k: kstat[k]["ms"])
     d = kstat[dom]
     avg_s = d["ms"] / d["calls"] * 1e-3
@@ -175,7 +176,10 @@ def trace_step(step_fn, ms_step, ops, fp=None, peak_flops=PEAK_BF16, NTR=3):
                     frac=round(fl_l / avg_s / peak_flops, 4), traffic=None)
     roof.update(kernel=dom, avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=d["calls"] // NTR,
                 algorithmic_bytes_per_launch=round(by_l), algorithmic_flops_per_launch=round(fl_l),
-                tflops=round(fl_l / avg_s / 1e12, 2), share_of_step=round(d["ms"] / NTR / ms_step, 3))
+                issued_flops_per_launch=round(d["issued"] / d["calls"]),
+                tflops=round(fl_l / avg_s / 1e12, 2), issued_tflops=round(d["issued"] / d["calls"] / avg_s / 1e12, 2),
+                share_of_step=round(d["ms"] / NTR / ms_step, 3),
+                traced_flops_per_step=sum(v["flops"] for v in kstat.values()) / NTR)
     # The weight-gradient products of a backward pass run on a second stream beside the main one, so the durations
     # above are those of kernels that SHARE the chip (their sum exceeds the step time).  For the quality of the
     # dominant kernel by itself, the same step is traced once more with every launch on one stream.
@@ -214,8 +218,11 @@ def attach_profiles(roof, kernels):
         tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
         tk = json.load(open(tf))["kernels"].get(roof["kernel"])
         if tk:
+            # a counter run of its own (PMC passes cannot run inside this process): stamped with the average launch
+            # duration of THAT run, so that figures from an older build of the kernel show as such
             roof["traffic"] = tk["traffic_bytes_per_launch"]
-            roof["traffic_source"] = os.path.relpath(tf, ROOT)
+            roof["traffic_source"] = dict(file=os.path.relpath(tf, ROOT), avg_launch_us_in_that_run=tk.get("avg_launch_us"),
+                                          launches_in_that_run=tk.get("launches"))
     except (IndexError, OSError, KeyError, ValueError):
         pass
     try:
@@ -486,6 +493,7 @@ def main():
 
     if rank == 0:
         macs = fwd_macs_per_sample()
+        roof_traced = roof["traced_flops_per_step"]
         out = dict(metric="denoiser_train_samples_per_sec", value=round(train_rate, 1), unit="samples/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype=a.dtype, data="synthetic",
@@ -493,6 +501,10 @@ def main():
                                         "BiRNN_score H=200 2 layers emb 128, full optimizer step, per-GPU batch 4096",
                                global_batch=B_LOCAL * world, per_gpu_batch=B_LOCAL, T=T, H=H, parallelism=f"dp{world}"),
                    model_flops_frac_of_bf16_peak=round(3 * 2 * macs * train_rate / (PEAK_BF16 * world), 4),
+                   # the algorithmic FLOPs the traced launches of one step add up to, against 3 x the forward's (a step
+                   # computes no gradient wrt the model's inputs, so the sum sits a few percent below 3 x)
+                   flops_check=dict(traced_per_step=roof.pop("traced_flops_per_step"), model_per_step=3.0 * 2.0 * macs * B_LOCAL,
+                                    ratio=round(roof_traced / (3.0 * 2.0 * macs * B_LOCAL), 4)),
                    roofline=roof, kernels=kernels, sampler=sampler, vae=vae, vae_h200=vae_h200, extras=extras)
         if not a.no_cpu_baseline and world == 1:
             note("CPU baseline (numpy oracle)")

@@ -401,6 +401,11 @@ int tad_copy_2d(int64_t rows, int64_t cols, const float* src, int64_t ld_src, fl
 /* out = a + b (float32 vectors): the bias of `input_proj(x) + cond_output(h)` computed as one product
  * (DIFF.py:197-198). */
 int tad_add_vec(int64_t n, const float* a, const float* b, float* out, tad_stream_t stream);
+/* p[0..n) = value: `torch.ones_like` masks of auto_loss's callers (VAE.py:222-253 evaluates the loss on outputs
+ * that already carry the mask) and of the post-hoc discriminator's labels (Evaluation/Metrics.py:101-106). */
+int tad_fill_f32(int64_t n, float* p, float value, tad_stream_t stream);
+/* p = 1 / (1 + exp(-p)) in place: `torch.sigmoid(logit)` of the post-hoc discriminator (Evaluation/Metrics.py:62-65). */
+int tad_sigmoid_f32(int64_t n, float* p, tad_stream_t stream);
 
 /* Minibatch of sliding windows straight from the [rows, F] table they are cut from
  * (dataprovider_pypots.py:75-87 `sliding_window` followed by the trainers' index gather, DIFF.py:320,
@@ -419,6 +424,11 @@ int tad_adam_step(int64_t n, float* p, const float* g, float* m, float* v, float
 void tad_adam_coefficients(float lr, float beta1, float beta2, int step, float* out2);
 int tad_adam_step_dev(int64_t n, float* p, const float* g, float* m, float* v, float beta1, float beta2, float eps,
                       float weight_decay, const float* coef2, tad_stream_t stream);
+/* The step counter of `optimizer.step()` (torch.optim.Adam's state['step'], DIFF.py:325, VAE.py:354) kept on the
+ * device for captured steps: coef4 = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step), step (int32 bits), unused};
+ * one single-thread launch increments the step and refreshes the two factors tad_adam_step_dev reads, so that a
+ * replayed graph needs nothing from the host. */
+int tad_adam_tick(float lr, float beta1, float beta2, float* coef4, tad_stream_t stream);
 
 /* ------------------------------------------------------------------ VAE family
  * reparametrize (VAE.py:147-150) + KLD partial sum (VAE.py:350-351):
@@ -472,7 +482,8 @@ int tad_metadata_noise(int64_t rows, int64_t F, int n_cols, const int32_t* cols,
  * an allocation.  No counterpart in the reference: it is for callers that cannot allocate (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  Same arguments and results as
  * tad_metadata_noise; n_cols beyond 64 is rejected.  All calls on one GPU share that GPU's array: calls that
- * overlap on one GPU (different streams) race; calls on one stream are ordered and each clears what it uses. */
+ * overlap on one GPU (different streams) race; calls on one stream are ordered and each clears what it uses.  The
+ * array used is that of the CURRENT device: a non-null stream of another device is rejected (TAD_ERR_INVALID). */
 int tad_metadata_noise_static(int64_t rows, int64_t F, int n_cols, const int32_t* cols, const float* cond, int64_t ld,
                               const float* noise, float level, float* out, int64_t ldo, tad_stream_t stream);
 

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Counter passes over one product of tad_mm16_nt (exp/nt_one.py N K); one rocprofv3 run per pass.
+# Counter passes over one product of tad_mm16_nt (scripts/nt_one.py N K); one rocprofv3 run per pass.
 # usage: scripts/pmc_mm16.sh [N K]
 set -e
 export TMPDIR=/tmp; R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/pmc16; rm -rf $O; mkdir -p $O; cd /tmp
 N=${1:-1600}; K=${2:-400}
-run() { n=$1; shift; timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -- python $R/exp/nt_one.py $N $K > $O/$n.log 2>&1; }
+run() { n=$1; shift; timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -- python $R/scripts/nt_one.py $N $K > $O/$n.log 2>&1; }
 run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY
 run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_ACTIVE_INST_ANY
 run sq3 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_LEVEL_WAVES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC

@@ -25,16 +25,36 @@ def per_kernel(d, counter):
     return acc
 
 
+def short_name(full):
+    m = re.search(r"(\w+<[^(]*>|\w+)\(", full.replace("(anonymous namespace)::", ""))
+    return m.group(1) if m else full
+
+
+def durations(d):
+    """{kernel: average launch duration in us} from the kernel trace of the same counter pass (durations under a
+    counter pass run a little long; they are there to date the figures, not to be quoted)."""
+    fs = glob.glob(f"{d}/**/*_kernel_trace.csv", recursive=True)
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    if fs:
+        for r in csv.DictReader(open(fs[0])):
+            a = acc[short_name(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-3
+    return {k: v[1] / v[0] for k, v in acc.items() if v[0]}
+
+
 def main():
     d, out = sys.argv[1], sys.argv[2]
     fe, wr = per_kernel(d + "/fetch", "FETCH_SIZE"), per_kernel(d + "/write", "WRITE_SIZE")
+    dur = durations(d + "/fetch")
     res = {}
     for k in sorted(set(fe) | set(wr)):
         nf, sf = fe.get(k, [0, 0.0])
         nw, sw = wr.get(k, [0, 0.0])
         rd = 2.0 * 1024.0 * sf / max(nf, 1)
         wb = 1024.0 * sw / max(nw, 1)
-        res[k] = dict(launches=nf, read_bytes_per_launch=round(rd), write_bytes_per_launch=round(wb), traffic_bytes_per_launch=round(rd + wb))
+        res[k] = dict(launches=nf, read_bytes_per_launch=round(rd), write_bytes_per_launch=round(wb), traffic_bytes_per_launch=round(rd + wb),
+                      avg_launch_us=round(dur[k], 2) if k in dur else None)
     # bytes per optimizer step: everything the process moved, over the number of steps it ran (one Adam launch each;
     # the synthetic-data generation at start-up is included, a fraction of a percent)
     steps = max((v["launches"] for k, v in res.items() if k.startswith("adam")), default=0)

@@ -17,7 +17,7 @@ from timeautodiff_amd.DIFF import BiRNN_score, DiffusionTrainer  # noqa: E402
 def table(summ, reps, title):
     print(f"==== {title}: ms per iteration, sorted")
     rows = []
-    for key, (cnt, ms, fl, by) in summ.items():
+    for key, (cnt, ms, fl, by, _issued) in summ.items():
         avg = ms / cnt
         rows.append((ms / reps, cnt / reps, avg, fl / avg / 1e9 if avg > 0 else 0, by / avg / 1e6 if avg > 0 else 0, key))
     rows.sort(reverse=True)

@@ -1,4 +1,4 @@
-"""Data parallelism rehearsed on ONE GPU: two fresh processes share the card, hold a gloo group over device tensors
+"""Data parallelism rehearsed on ONE GPU: two (or eight) fresh processes share the card, hold a gloo group over device tensors
 and run the trainers' real entry points (DiffusionTrainer.step, VAETrainer.train_step / eval_loss, DIFF.sample) with
 ``process_group``; the result must equal the one-process run on the same draws.  The global batch (7, validation 5,
 sampling 5) is not divisible by the number of ranks.  fp32; tolerances: 2e-5 relative on losses and gradients (the
@@ -26,14 +26,19 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def test_two_ranks_on_one_gpu_equal_one_process(tmp_path):
+@pytest.mark.parametrize("world,grad_stream", [(2, "0"), (2, "1"), (8, "0")])
+def test_ranks_on_one_gpu_equal_one_process(tmp_path, world, grad_stream):
+    """world 2: the ranks take 3 / 4 of the 7 training windows; with TAD_GRAD_STREAM=1 the weight gradients and the first
+    bucket's all-reduce go through the second stream.  world 8: one rank's training shard and three ranks' validation
+    and sampling shards are EMPTY (7 and 5 items over 8 ranks) -- every rank still takes part in every collective."""
     worker = os.path.join(HERE, "dp_gpu_worker.py")
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
-    subprocess.run([sys.executable, worker, "0", "1", "0", one], check=True, timeout=300)
+    env = dict(os.environ, TAD_GRAD_STREAM=grad_stream)
+    subprocess.run([sys.executable, worker, "0", "1", "0", one], check=True, timeout=300, env=env)
     port = _port()
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), two]) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), two], env=env) for r in range(world)]
     for p in procs:
-        assert p.wait(timeout=300) == 0
+        assert p.wait(timeout=600) == 0
     a, b = np.load(one), np.load(two)
     # denoiser: loss of every step, the reduced gradient of the first step (and its norm, the cross-rank equality
     # check a training loop would use), the weights after three steps
@@ -44,7 +49,7 @@ def test_two_ranks_on_one_gpu_equal_one_process(tmp_path):
     assert _rel(b["den_w"], a["den_w"]) < 1e-4
     # sampler: every rank returns the whole batch, identical to the one-process trajectory; local_only returns the slice
     assert b["sample"].shape == a["sample"].shape and _rel(b["sample"], a["sample"]) < 1e-6
-    assert int(b["sample_local_rows"][0]) == 2 and int(a["sample_local_rows"][0]) == 5
+    assert int(b["sample_local_rows"][0]) == (5 * 1) // world and int(a["sample_local_rows"][0]) == 5       # rank 0's slice
     # VAE: total loss, all loss parts (bce, mse, ce per column, kld sums), validation loss, gradient, weights
     assert np.max(np.abs(a["vae_loss"] - b["vae_loss"]) / np.abs(a["vae_loss"])) < 2e-5
     assert np.max(np.abs(a["vae_parts"] - b["vae_parts"]) / np.maximum(np.abs(a["vae_parts"]), 1e-6)) < 2e-5

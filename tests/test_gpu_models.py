@@ -358,18 +358,28 @@ def test_train_autoencoder_loss_curve_vs_reference_golden(dev, name, fn):
 
 
 # ------------------------------------------------------------------ properties at benchmark size
-def test_denoiser_fullsize_properties(dev):
-    """energy-like shape at the benchmark batch (B=4096, T=24, H=200, bf16): rows are
+FULLSIZE = {
+    # name: (schema, denoiser H, T, windows per launch, mask of the VAE run)
+    "energy_T24_H200": (dict(n_bins=0, n_cats=1, n_nums=27, cards=[8]), 200, 24, 4096, "ones"),
+    "metro_T48_H512": (dict(n_bins=0, n_cats=3, n_nums=5, cards=[12, 1, 11]), 512, 48, 4096, "bern"),
+    "airq_T48_H512": (dict(n_bins=0, n_cats=0, n_nums=13, cards=[]), 512, 48, 4096, "bern"),
+}
+
+
+@pytest.mark.parametrize("name", list(FULLSIZE))
+def test_denoiser_fullsize_properties(dev, name):
+    """The benchmark batch (4096 windows, bf16) at the energy shape (T=24, H=200) and at the Metro / AirQuality shapes
+    (T=48, H=512: 32-row workgroups with two chunks of hidden units per wave): rows are
     independent (a sub-batch reproduces its rows of the big batch) and the gradient is
     additive over batch halves under the same global denominator."""
     from timeautodiff_amd import DIFF
-    s = dict(n_bins=0, n_cats=1, n_nums=27, cards=[8])
-    sch = Schema(0, 1, 27, [8])
-    B, T, K, H = 4096, 24, 6, 200
+    s, H, T, B, _ = FULLSIZE[name]
+    K = 6
+    F = s["n_bins"] + s["n_cats"] + s["n_nums"]
     data = fu.make_data(s, N=B, T=T, K=K, seed=1, mask_kind="ones")
     data["cond"] = data["data"]
     torch.manual_seed(5)
-    m = DIFF.BiRNN_score(K, 28, H, 2, 100, 8, 128, 0, 1, 27, [8])
+    m = DIFF.BiRNN_score(K, F, H, 2, 100, 8, 128, s["n_bins"], s["n_cats"], s["n_nums"], list(s["cards"]))
     m.set_compute_dtype("bf16")
     eng = m.engine(dev)
     g = torch.Generator().manual_seed(6)
@@ -395,6 +405,142 @@ def test_denoiser_fullsize_properties(dev):
     assert abs(l_all - (l_a + l_b)) < 1e-5 * l_all
     gs = g_a + g_b
     assert float((g_all - gs).abs().max()) < 1e-3 * float(g_all.abs().max())           # atomics reorder sums only
+
+
+@pytest.mark.parametrize("name", list(FULLSIZE))
+def test_vae_fullsize_properties(dev, name):
+    """DeapStack at the reference's hidden size 512 (VAE.py:119-120) on 4096 windows, bf16 -- the launch shapes the bench
+    times (32-row workgroups, two chunks of hidden units per wave, the GRU's backward gate by gate), with the masked mixed
+    loss (Metro / AirQuality: Bernoulli(0.1) point mask and a cond): the latents and head outputs of a window do not
+    depend on the batch it is computed in (bit exact), the loss parts add up over batch halves, and so do the gradients
+    under the same global denominators."""
+    s, _, T, B, mk = FULLSIZE[name]
+    sch = Schema(s["n_bins"], s["n_cats"], s["n_nums"], list(s["cards"]))
+    L, beta = 6, 0.05
+    ae = _make_vae(dict(H=512, E=128, L=L, seed=7), sch, dev, "bf16")
+    eng = ae.engine(dev)
+    data = fu.make_data(s, N=B, T=T, K=L, seed=8, mask_kind=mk)
+    inp = T_(data["response"] + data["cond"], dev)
+    mask, cond = T_(data["mask"], dev), T_(data["cond"], dev)
+    target = inp * mask
+    eps = torch.randn(B, T, L, generator=torch.Generator().manual_seed(9)).to(dev)
+    nparts = 3 + max(sch.n_cats, 1)
+    rows_glob = B * T
+
+    def run(lo, hi):
+        eng.fp.zero_grad()
+        parts = torch.zeros(nparts, device=dev)
+        c = lambda a: a[lo:hi].contiguous()     # noqa: E731
+        zz, mu, lv = eng.encoder(c(inp), c(eps), train=True, kld_sum=parts[2 + max(sch.n_cats, 1):])
+        heads = eng.decoder(zz, c(mask), c(cond), target=c(target), scales=eng.loss_scales(rows_glob), loss_parts=parts, train=True)
+        keep = (zz.clone(), mu.clone(), heads.clone())
+        eng.backward(beta, rows_glob)
+        torch.cuda.synchronize()
+        return keep, parts.double().cpu(), eng.fp.gflat[:eng.fp.n_active].clone()
+    (z_all, mu_all, h_all), p_all, g_all = run(0, B)
+    (z_a, mu_a, h_a), p_a, g_a = run(0, B // 2)
+    (z_b, mu_b, h_b), p_b, g_b = run(B // 2, B)
+    assert torch.isfinite(h_all).all() and torch.isfinite(g_all).all() and float(g_all.abs().max()) > 0
+    hr = (B // 2) * T
+    assert torch.equal(z_all[:B // 2], z_a) and torch.equal(z_all[B // 2:], z_b)       # row independence, bit exact
+    assert torch.equal(mu_all[:B // 2], mu_a) and torch.equal(mu_all[B // 2:], mu_b)
+    assert torch.equal(h_all[:hr], h_a) and torch.equal(h_all[hr:], h_b)
+    assert float((p_all - (p_a + p_b)).abs().max()) < 1e-4 * float(p_all.abs().max())
+    assert float((g_all - (g_a + g_b)).abs().max()) < 1e-3 * float(g_all.abs().max())   # atomics reorder sums only
+
+
+# ------------------------------------------------------------------ bf16 loss-curve windows
+BF16_CURVE_TOL = 2e-2    # bf16 training loop vs the bf16-emulating oracle's loop, per-iteration loss, relative
+BF16_CURVE_REF_TOL = 5e-2   # bf16 training loop vs the fp32 reference's recorded curve, per-iteration loss, relative
+
+
+def test_train_diffusion_bf16_loss_curve_window(dev):
+    """The mode the bench times (bf16 operands, bf16-stored products) through 20 optimizer steps on the reference's
+    recorded draws (DIFF.py:305-328): the loss of every iteration against the oracle's loop that rounds at the kernels'
+    rounding points (2e-2: one step agrees to 5e-3, Adam's first steps move every weight by lr whatever the size of
+    its gradient, so rounding-level gradient differences grow for a few steps before the curve contracts them), and
+    against the fp32 reference's recorded curve at the stated looser bf16 tolerance of 5e-2."""
+    from oracle import loops as oloops
+    from timeautodiff_amd import DIFF
+    from test_oracle_golden import replay_diffusion_draws
+    z, meta = fu.load("diffloop_numeric")
+    sch = _schema(meta)
+    N, T, K, H, steps = meta["N"], meta["T"], meta["K"], meta["H"], meta["steps"]
+    data = fu.make_data(meta["schema"], N=N, T=T, K=K, seed=meta["seed"], mask_kind="ones")
+    random.seed(meta["seed"])
+    torch.manual_seed(meta["seed"])
+    m = DIFF.BiRNN_score(K, sch.n_bins + sch.n_cats + sch.n_nums, H, 2, 100, 8, 128, sch.n_bins, sch.n_cats, sch.n_nums, sch.cards)
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    draws = list(replay_diffusion_draws(N, T, K, steps))
+    tr = DIFF.DiffusionTrainer(m, torch.from_numpy(data["latent"]), torch.from_numpy(data["time_info"]), torch.from_numpy(data["cond"]),
+                               dtype="bf16", dev=dev)
+    assert tr.eng.mm16                                   # the bf16-stored-operand path, as in the bench
+    hist = torch.zeros(steps, device=dev)
+    for k, d in enumerate(draws):
+        tr.step(draw=dict(idx=torch.tensor(d["idx"]), t=torch.from_numpy(d["t"]), i=torch.from_numpy(d["i"]),
+                          noise=torch.from_numpy(d["noise"])), loss_out=hist[k:k + 1])
+    got = hist.cpu().numpy().astype(np.float64)
+    _, alphas = oops.schedule(100)
+    with oops.bf16_operands(storage=True):
+        ref16 = np.array(oloops.train_diffusion_steps(sd, data["latent"], data["time_info"], data["cond"], sch, draws, alphas))
+    e16 = np.max(np.abs(got - ref16) / np.abs(ref16))
+    e32 = np.max(np.abs(got - z["losses"]) / np.abs(z["losses"]))
+    print("bf16 loss curve: vs emulating oracle %.3g, vs fp32 reference %.3g" % (e16, e32))
+    assert e16 < BF16_CURVE_TOL and e32 < BF16_CURVE_REF_TOL
+    # the weights after the window: norms against the emulating oracle's
+    sd_dev = m.state_dict()
+    for k, v in sd.items():
+        if not k.startswith("Emb_hidden"):
+            a, b = fu.stats(sd_dev[k].cpu().numpy())[1], fu.stats(v)[1]
+            assert abs(a - b) < 1e-2 * max(b, 1e-6), k
+
+
+@pytest.mark.parametrize("name,select", [("vaeloop_mixed_val", "val"), ("vaeloop_mixed_train", "train")])
+def test_train_autoencoder_bf16_loss_curve_window(dev, name, select):
+    """VAE.train_autoencoder / _best_train in bf16 through the reference's 30 recorded iterations (VAE.py:320-388,
+    477-547; train loss, validation loss, beta annealing, best-state rule): both curves against the bf16-emulating
+    oracle's loop at 2e-2 and against the fp32 reference's recorded curves at 5e-2."""
+    from oracle import loops as oloops
+    from timeautodiff_amd import VAE
+    from test_host_logic import StubParser
+    z, meta = fu.load(name)
+    sch = _schema(meta)
+    N, Nv, T, L, B, steps = meta["N"], meta["Nv"], meta["T"], meta["L"], meta["B"], meta["steps"]
+    tr = fu.make_data(meta["schema"], N=N, T=T, K=L, seed=meta["seed"], mask_kind="bern")
+    va = fu.make_data(meta["schema"], N=Nv, T=T, K=L, seed=meta["seed"] + 100, mask_kind="bern")
+    dd = dict(parser=StubParser(meta["schema"]),
+              response_train=torch.from_numpy(tr["response"]), cond_train=torch.from_numpy(tr["cond"]),
+              target_mask_train=torch.from_numpy(tr["mask"]).int(),
+              response_val=torch.from_numpy(va["response"]), cond_val=torch.from_numpy(va["cond"]),
+              target_mask_val=torch.from_numpy(va["mask"]).int())
+    fn = "train_autoencoder" if select == "val" else "train_autoencoder_best_train"
+    random.seed(meta["seed"])
+    torch.manual_seed(meta["seed"])
+    ae, latent, output, hist = getattr(VAE, fn)(None, 1, meta["H"], 2, meta["lr"], meta["wd"], steps, B, 1, meta["min_beta"],
+                                                meta["max_beta"], meta["E"], 8, L, "cuda", dd, noise_source="reference", dtype="bf16")
+    # the oracle's loop on the same draws (same seeds, same order: parameter init, then per iteration indices, eps, eps_val)
+    random.seed(meta["seed"])
+    torch.manual_seed(meta["seed"])
+    F = sch.n_bins + sch.n_cats + sch.n_nums
+    sd = {k: v.numpy().copy() for k, v in
+          VAE.init_vae_state(sch.n_bins, sch.n_cats, sch.n_nums, sch.cards, F, meta["H"], 2, meta["E"], 8, L).items()}
+
+    def draws():
+        for _ in range(steps):
+            idx = random.sample(list(range(N)), B)
+            yield dict(idx=idx, eps_train=torch.randn(B, T, L).numpy(), eps_val=torch.randn(Nv, T, L).numpy())
+    data = dict(response_train=tr["response"], cond_train=tr["cond"], target_mask_train=tr["mask"],
+                response_val=va["response"], cond_val=va["cond"], target_mask_val=va["mask"])
+    with oops.bf16_operands(storage=True):
+        ohist, _, _ = oloops.train_autoencoder_steps(sd, data, sch, draws(), meta["lr"], meta["wd"], meta["min_beta"], meta["max_beta"],
+                                                     select=select)
+    for k in ("train", "val"):
+        got = np.array(hist[k], np.float64)
+        e16 = np.max(np.abs(got - np.array(ohist[k])) / np.abs(np.array(ohist[k])))
+        e32 = np.max(np.abs(got - z[k]) / np.abs(z[k]))
+        print("bf16 VAE %s curve: vs emulating oracle %.3g, vs fp32 reference %.3g" % (k, e16, e32))
+        assert e16 < BF16_CURVE_TOL and e32 < BF16_CURVE_REF_TOL, k
+    assert not latent.requires_grad and torch.isfinite(latent).all()
 
 
 def test_sampler_fullsize_sharding_invariance(dev):

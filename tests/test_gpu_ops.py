@@ -334,15 +334,31 @@ def test_rnn_fwd_bwd(ops, dev, cell, prec, B, T, H, IN):
     _check_rnn(r, cell, B, T, H, F32_TOL if prec == 0 else BF16_EMU_TOL)
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("H", [200, 512])
 @pytest.mark.parametrize("cell", [0, 1])
-def test_rnn_full_batch_forms(ops, dev, cell):
-    """At 4096+ windows per launch the sequence kernels take other forms than at the small batches above (bf16: the
-    LSTM forward as two rounds of 16-row workgroups with resident W_hh, the GRU forward at 32 rows with resident W_hh,
-    the backward at 32 rows with most of the transposed W_hh in LDS and registers): the same outputs, stash and
-    gradients against the oracle, on a batch that leaves the last workgroup ragged."""
-    B, T, H, IN = 4100, 2, 200, 24
-    rng = np.random.default_rng(4100 + cell)
-    r = _run_rnn(ops, dev, cell, 1, B, T, H, [False, True], rng, IN=IN)
+def test_rnn_full_batch_forms(ops, dev, cell, H, prec):
+    """At 4096+ windows per launch the sequence kernels take other forms than at the small batches above (bf16, H = 200:
+    the LSTM forward as two rounds of 16-row workgroups with resident W_hh, the GRU forward at 32 rows with resident W_hh,
+    the backward at 32 rows with most of the transposed W_hh in LDS and registers; H = 512, the hidden size of every
+    reference VAE and of the Metro / AirQuality denoisers: 32 rows per workgroup with two chunks of hidden units per wave,
+    the GRU's backward gate by gate): the same outputs, stash and gradients against the oracle, on a batch that leaves
+    the last workgroup ragged.  fp32 at the same sizes: 1e-4."""
+    B, T, IN = 4100, 2, 24
+    rng = np.random.default_rng(4100 + cell + H + prec)
+    r = _run_rnn(ops, dev, cell, prec, B, T, H, [False, True], rng, IN=IN)
+    assert r["s16"] == bool(prec)
+    _check_rnn(r, cell, B, T, H, BF16_EMU_TOL if prec else F32_TOL)
+
+
+@pytest.mark.parametrize("cell", [0, 1])
+def test_rnn_heads_layout_at_hidden_512(ops, dev, cell):
+    """The VAE encoders' launch shape (reference VAE.py:119-120, 154-155): two heads that both run forward in time over
+    one shared input, hidden 512, full 32-row workgroups, three steps (so that the recurrent gradient crosses two
+    step boundaries), against the oracle."""
+    B, T, H, IN = 4100, 3, 512, 32
+    rng = np.random.default_rng(512 + cell)
+    r = _run_rnn(ops, dev, cell, 1, B, T, H, [False, False], rng, IN=IN)
     assert r["s16"]
     _check_rnn(r, cell, B, T, H, BF16_EMU_TOL)
 

@@ -112,3 +112,40 @@ def test_metric_functions_end_to_end():
     pl = []
     mae = Metrics.predictive_score_metrics(real, same, 1, iterations=200, batch_size=64, losses=pl)
     assert np.isfinite(mae) and mae < 0.5 and pl[-1] < pl[0]
+
+
+def test_discriminator_step_with_halves_of_different_length_vs_oracle():
+    """Fewer generated training windows than the batch size: the reference's batch_generator then returns a shorter
+    generated half, and each BCE mean runs over its own count (Evaluation/Metrics.py:96-106).  Loss and every gradient of
+    such a step against the oracle (the equal-length goldens do not cover it: parity here is pinned by the oracle, which
+    those goldens pin)."""
+    from oracle import posthoc as opost
+    from timeautodiff_amd import Metrics, ops
+    z, meta = fu.load("posthoc_disc")
+    dev = torch.device("cuda:0")
+    dim = meta["dim"]
+    disc = Metrics.Discriminator(dim, meta["hidden"], meta["layers"])
+    sd = fu.sub(z, "w")
+    _load_into(disc, sd)
+    nr, nf = 7, 4
+    real, fake = z["real"][:nr], z["fake"][:nf]
+    oloss, _, _, ograds = opost.disc_loss_and_grads({k: v.copy() for k, v in sd.items()}, real, fake, meta["layers"])
+    eng = disc.engine(dev)
+    xb = torch.from_numpy(np.concatenate([real, fake], 0)).to(dev).contiguous()
+    yb = torch.empty(nr + nf, 1, device=dev)
+    ops.fill_(yb[:nr], 1.0)
+    ops.fill_(yb[nr:], 0.0)
+    ones = ops.fill_(torch.empty(nr + nf, 1, device=dev), 1.0)
+    eng.disc_step_body(xb, yb, ones, (nr, nf), False, lr=0.0)
+    torch.cuda.synchronize()
+    l4 = eng.loss4.cpu().numpy().astype(np.float64)
+    assert abs(l4[0] / nr + l4[2] / nf - oloss) < TOL * oloss
+    for k, g in ograds.items():
+        assert fu.rel_err(eng.fp.g(k).cpu().numpy(), g.reshape(eng.fp.g(k).shape)) < TOL, k
+    # and the metric end to end on sets of different sizes (100 real windows, 40 generated ones: 80 / 32 for training)
+    rng = np.random.default_rng(6)
+    a, b = rng.random((100, 12, 4), dtype=np.float32), np.clip(rng.random((40, 12, 4), dtype=np.float32) * 0.3, 0, 1)
+    np.random.seed(0)
+    losses = []
+    s = Metrics.discriminative_score_metrics(torch.from_numpy(a), torch.from_numpy(b), 60, losses=losses)
+    assert len(losses) == 60 and np.isfinite(losses).all() and losses[-1] < losses[0] and 0.0 <= s <= 0.5

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tad_abi_version() == 10
+    assert lib.tad_abi_version() == 11
     # bf16, H = 200, LSTM: the forward buffer holds the 32-row-form image (7 chunks x 13 k-blocks x 4 gates) and the
     # 16-row-form image (7 x 7 k-steps x 4 gates x 2 blocks of 16 units), the backward one 7 x 52 k-blocks; 1 KiB each
     assert lib.tad_rnn_packed_bytes(1, 200, 4) == max(7 * 13 * 4 + 7 * 7 * 4 * 2, 7 * (4 * 224 // 16)) * 1024
@@ -164,3 +164,93 @@ def test_data_parallel_equals_single_process_gloo():
     assert fu.rel_err(ret["flat"], flat_ref) < 5e-5
     assert abs(ret["loss"] - float(z["loss"])) < 1e-5 * float(z["loss"])
     assert fu.rel_err(ret["pred"], z["pred"]) < 2e-5
+
+
+def _dp8_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from oracle import denoiser as oden, ops as oops
+        from oracle.denoiser import Schema
+        from timeautodiff_amd.dist import DataParallelPlan
+        sd, sch_d, data, t, i_idx, noise, B, Bs = _dp8_problem()
+        sch = Schema(sch_d["n_bins"], sch_d["n_cats"], sch_d["n_nums"], list(sch_d["cards"]))
+        T, K = data["latent"].shape[1:]
+        _, alphas = oops.schedule(100)
+        keys = sorted(k for k in sd if not k.startswith("Emb_hidden"))
+        nflat = sum(sd[k].size for k in keys)
+        # the trainers' buffer: gradients, then the loss partial sum in the slot right behind them -- ONE all-reduce
+        flat = torch.zeros(nflat + 1, dtype=torch.float64)
+        plan = DataParallelPlan(B, True)
+        lo, hi = plan.lo, plan.hi
+        assert hi - lo in (B // world, B // world + 1)
+        loss, pred, grads = oden.loss_and_grads(sd, data["latent"][lo:hi], t[lo:hi], i_idx[lo:hi], noise[lo:hi], data["time_info"][lo:hi],
+                                                data["cond"][lo:hi], sch, alphas, global_numel=B * T * K)
+        flat[:nflat] = torch.from_numpy(np.concatenate([grads[k].ravel() for k in keys]).astype(np.float64))
+        flat[nflat] = loss * (hi - lo) * T * K
+        first = nflat // 2
+        pending = [plan.all_reduce_async(flat[:first]), plan.all_reduce_async(flat[first:])]
+        for w in pending:
+            w.wait()
+        # a batch smaller than the world (sampling / validation of Bs = 5 items over 8 ranks): three ranks own nothing,
+        # still take part in the collectives, and contribute zeros / zero rows
+        splan = DataParallelPlan(Bs, True)
+        slo, shi = splan.lo, splan.hi
+        part = torch.zeros(2, dtype=torch.float64)
+        mine = torch.zeros(shi - slo, T, K)
+        if shi > slo:
+            i0 = np.zeros((shi - slo, T, 1), np.float32)
+            p, _ = oden.forward(sd, data["latent"][slo:shi], t[slo:shi], i0, data["time_info"][slo:shi], data["cond"][slo:shi], sch)
+            mine = torch.from_numpy(p.astype(np.float32))
+            part[0], part[1] = float((p.astype(np.float64) ** 2).sum()), shi - slo
+        plan.all_reduce(part)
+        whole = splan.all_gather_cat(mine)
+        ret[rank] = (shi - slo, tuple(whole.shape))
+        if rank == world - 1:          # every rank holds the same results: take them from the last one
+            ret["flat"] = flat.numpy()
+            ret["part"] = part.numpy()
+            ret["whole"] = whole.numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp8_problem():
+    from timeautodiff_amd import DIFF
+    sch_d = fu.SCHEMAS["mixed"]
+    B, Bs, T, K, H, E = 100, 5, 4, 3, 8, 8
+    torch.manual_seed(3)
+    sd = {k: v.numpy().copy() for k, v in DIFF.init_denoiser_state(K, H, 2, 100, 8, E, sch_d["n_bins"], sch_d["n_cats"], sch_d["n_nums"],
+                                                                   sch_d["cards"]).items()}
+    data = fu.make_data(sch_d, N=B, T=T, K=K, seed=4, mask_kind="ones")
+    rng = np.random.default_rng(5)
+    t = np.sort(rng.random((B, T, 1), dtype=np.float32), 1)
+    return sd, sch_d, data, t, rng.integers(0, 100, B), rng.standard_normal((B, T, K)).astype(np.float32), B, Bs
+
+
+def test_data_parallel_world_8_with_uneven_and_empty_shards_gloo():
+    """The reference's batch of 100 windows over 8 ranks (shards of 12 and 13), gradients and the loss slot reduced as the
+    trainers reduce them (two asynchronous buckets of one flat buffer), and a batch of 5 over 8 ranks (three empty
+    shards) through the partial-sum reduction and the padded all-gather: equal to one process."""
+    from oracle import denoiser as oden, ops as oops
+    from oracle.denoiser import Schema
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp8_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    sd, sch_d, data, t, i_idx, noise, B, Bs = _dp8_problem()
+    sch = Schema(sch_d["n_bins"], sch_d["n_cats"], sch_d["n_nums"], list(sch_d["cards"]))
+    T, K = data["latent"].shape[1:]
+    _, alphas = oops.schedule(100)
+    loss, _, grads = oden.loss_and_grads(sd, data["latent"], t, i_idx, noise, data["time_info"], data["cond"], sch, alphas)
+    keys = sorted(k for k in sd if not k.startswith("Emb_hidden"))
+    ref = np.concatenate([grads[k].ravel() for k in keys])
+    flat = ret["flat"]
+    assert fu.rel_err(flat[:-1], ref) < 1e-5
+    assert abs(flat[-1] / (B * T * K) - loss) < 1e-6 * abs(loss)
+    assert sorted(ret[r][0] for r in range(world)) == [0, 0, 0, 1, 1, 1, 1, 1]
+    assert all(ret[r][1] == (Bs, T, K) for r in range(world))
+    p, _ = oden.forward(sd, data["latent"][:Bs], t[:Bs], np.zeros((Bs, T, 1), np.float32), data["time_info"][:Bs], data["cond"][:Bs], sch)
+    assert fu.rel_err(ret["whole"], p) < 1e-5
+    assert ret["part"][1] == Bs and abs(ret["part"][0] - float((p.astype(np.float64) ** 2).sum())) < 1e-5 * ret["part"][0]

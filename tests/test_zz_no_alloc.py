@@ -1,5 +1,6 @@
 """tad_metadata_noise_static (the entry point that allocates nothing: column statistics in a device array of the
-library) against tad_metadata_noise (caller-provided workspace), through the C ABI: bit-identical results on two
+library) against tad_metadata_noise (caller-provided workspace), through the C ABI: the same results (to about one
+unit in the last place: the column statistics are sums of float64 atomics, whose order differs from run to run) on two
 calls in a row, the second with a smaller input, so stale contents of the shared array would show."""
 import ctypes as C
 

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import ops
 from .dist import DataParallelPlan
-from .engine import CounterNoise, DenoiserEngine, prec_of
+from .engine import CounterNoise, DenoiserEngine, Workspace, prec_of, use_workspace
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
@@ -256,7 +256,9 @@ class DiffusionTrainer:
                              "order) or 'device' (one counter-based draw kernel on the device)")
         self.all_indices = list(range(self.N))
         nb = self.plan.local_count
-        ws = self.eng.ws
+        # the steps run in a workspace of the trainer's own: model(...), get_loss and sample() between two steps re-size
+        # the engine's default workspace, and a captured step holds the addresses of the buffers it was captured on
+        ws = self.ws = Workspace(d)
         self.bx = ws.get("batch.x", (nb, self.T, self.K))
         self.bt = ws.get("batch.time_info", (nb, self.T, self.time_info.shape[2]))
         self.bc = ws.get("batch.cond", (nb, self.T, self.cond.shape[2]))
@@ -301,9 +303,10 @@ class DiffusionTrainer:
     def step(self, draw=None, loss_out=None):
         """One optimizer step (reference DIFF.py:306-325).  ``loss_out`` (1-element device
         tensor view) receives the mean loss of the global batch without a host sync."""
-        if self.use_graph():
-            return self._step_graph(draw, loss_out)
-        return self._step_eager(draw, loss_out)
+        with use_workspace(self.eng, self.ws):
+            if self.use_graph():
+                return self._step_graph(draw, loss_out)
+            return self._step_eager(draw, loss_out)
 
     def _step_graph(self, draw, loss_out):
         """The step as a replay of its captured graph; the draws (a handful of launches) stay outside, in the order
@@ -323,8 +326,6 @@ class DiffusionTrainer:
             B, T, K = self.B, self.T, self.K
             self._g_in = dict(idx=torch.zeros(B, dtype=torch.int64, device=d), t=torch.zeros(B, T, 1, device=d),
                               i=torch.zeros(B, dtype=torch.int32, device=d), noise=torch.zeros(B, T, K, device=d))
-            self._g_coef = torch.zeros(2, device=d)
-            self._g_coef_host = torch.zeros(2).pin_memory()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -335,7 +336,7 @@ class DiffusionTrainer:
         gi["t"].copy_(dr["t"], non_blocking=True)
         gi["i"].copy_(dr["i"], non_blocking=True)
         gi["noise"].copy_(dr["noise"], non_blocking=True)
-        eng.fp.adam_refresh(self.lr, self._g_coef, self._g_coef_host)
+        eng.fp.adam_before_replay()
         self._graph.replay()
         if loss_out is not None:
             torch.div(self.loss_sum, float(self.B * self.T * self.K), out=loss_out)
@@ -350,7 +351,7 @@ class DiffusionTrainer:
         eng.loss_and_grads(self.bx, t, i_idx, noise, self.bt, self.bc, self.alphas, self.loss_sum,
                            global_numel=self.B * self.T * self.K)
         if captured:
-            eng.fp.adam_captured(self._g_coef)
+            eng.fp.adam_captured(self.lr)
         else:
             eng.fp.adam(self.lr)
 

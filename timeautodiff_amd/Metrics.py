@@ -47,7 +47,10 @@ class PosthocEngine:
         self.fp = FlatParams(module, layout, [], self.device)
         self.rnn = RnnStack(self.fp, CELL_GRU, hidden, in_dim, num_layers, dirs, "heads", self.prec)
         self.ws = Workspace(self.device)
-        self.loss = self.fp.slots(1)
+        # loss partial sums right behind the gradients (cleared with them): [0] the step's loss sum (both halves of a
+        # discriminator batch when they are equally long), [2] the generated half's when the halves differ in length
+        self.loss4 = self.fp.slots(4)
+        self.loss = self.loss4[:1]
         self._graphs = {}
 
     def forward(self, x, train=False):
@@ -82,15 +85,21 @@ class PosthocEngine:
 
     # ---- one optimizer step each (everything after the draws; capturable)
     def disc_step_body(self, xb, yb, ones, n_each, captured, coef=None, lr=1e-3):
-        """xb [2n,T,dim] = real windows then fake ones, yb [2n,1] = their labels: d_loss = mean BCE(real) + mean
-        BCE(fake) (reference Metrics.py:101-106) -> backward -> Adam."""
+        """xb [n_real + n_fake, T, dim] = real windows then generated ones, yb = their labels: d_loss = mean BCE(real)
+        + mean BCE(fake), each mean over its own count (reference Metrics.py:101-106) -> backward -> Adam.  n_each: the
+        common count, or (n_real, n_fake) -- then loss4[0] / n_real + loss4[2] / n_fake is the step's loss."""
         self.fp.zero_grad()
         logit = self.forward(xb, train=True)
         dlog = self.ws.get("dlogit", tuple(logit.shape))
-        ops.vae_heads_loss(logit, ones, yb, 1, 0, 0, [], 1.0 / n_each, 0.0, 0.0, dlog, self.loss)
+        nr, nf = (n_each, n_each) if isinstance(n_each, int) else n_each
+        if nr == nf:
+            ops.vae_heads_loss(logit, ones, yb, 1, 0, 0, [], 1.0 / nr, 0.0, 0.0, dlog, self.loss4[:2])
+        else:
+            ops.vae_heads_loss(logit[:nr], ones[:nr], yb[:nr], 1, 0, 0, [], 1.0 / nr, 0.0, 0.0, dlog[:nr], self.loss4[:2])
+            ops.vae_heads_loss(logit[nr:], ones[nr:], yb[nr:], 1, 0, 0, [], 1.0 / nf, 0.0, 0.0, dlog[nr:], self.loss4[2:])
         self.backward(dlog)
         if captured:
-            self.fp.adam_captured(coef)
+            self.fp.adam_captured(lr)
         else:
             self.fp.adam(lr)
 
@@ -102,7 +111,7 @@ class PosthocEngine:
         ops.l1_loss(p, yb, 1.0 / p.numel(), dp, self.loss)
         self.backward(dp)
         if captured:
-            self.fp.adam_captured(coef)
+            self.fp.adam_captured(lr)
         else:
             self.fp.adam(lr)
 
@@ -116,14 +125,13 @@ class PosthocEngine:
                 body(False, None)
             fp.flat.copy_(keep[0]); fp.m.copy_(keep[1]); fp.v.copy_(keep[2]); fp.step = keep[3]
             fp.version += 1
-            coef = torch.zeros(2, device=self.device)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                body(True, coef)
-            ent = self._graphs[key] = (g, coef)
-        g, coef = ent
-        self.fp.adam_refresh(lr, coef)
+                body(True, None)
+            ent = self._graphs[key] = (g, None)
+        g, _ = ent
+        self.fp.adam_before_replay()
         g.replay()
 
 
@@ -154,7 +162,7 @@ class Discriminator(nn.Module):
         eng = self.engine(x.device if x.is_cuda else None)
         eng.fp.version += 1
         logit = eng.forward(x.to(device=eng.device, dtype=torch.float32).contiguous()).clone()
-        return logit, torch.sigmoid(logit)
+        return logit, ops.sigmoid_(logit.clone())
 
 
 class PosthocRNN(nn.Module):
@@ -192,25 +200,32 @@ def discriminative_score_metrics(ori_data, generated_data, iterations, *, dtype=
     disc._dtype = dtype
     eng = disc.engine(dev)
     train_x, train_x_hat, test_x, test_x_hat = train_test_divide(ori, gen)
-    nb = min(batch_size, len(train_x), len(train_x_hat))
-    xb = torch.zeros(2 * nb, seq_len, dim, device=dev)
-    yb = torch.cat([torch.ones(nb, 1, device=dev), torch.zeros(nb, 1, device=dev)], 0)
-    ones = torch.ones(2 * nb, 1, device=dev)
-    hist = torch.zeros(max(iterations, 1), device=dev)
+    # the reference's batch_generator takes the first batch_size entries of a permutation of EACH set: the two halves
+    # of a batch differ in length when one set holds fewer than batch_size training windows, and each BCE mean runs
+    # over its own count (Metrics.py:96-106)
+    n_real, n_fake = min(batch_size, len(train_x)), min(batch_size, len(train_x_hat))
+    xb = torch.empty(n_real + n_fake, seq_len, dim, device=dev)
+    yb = torch.empty(n_real + n_fake, 1, device=dev)
+    ops.fill_(yb[:n_real], 1.0)
+    ops.fill_(yb[n_real:], 0.0)
+    ones = ops.fill_(torch.empty(n_real + n_fake, 1, device=dev), 1.0)
+    hist = torch.zeros(max(iterations, 1), 4, device=dev)
+    n_each = n_real if n_real == n_fake else (n_real, n_fake)
     with torch.cuda.device(dev):
         for itt in range(iterations):
-            ir = torch.from_numpy(np.random.permutation(len(train_x))[:batch_size][:nb]).to(dev)
-            ih = torch.from_numpy(np.random.permutation(len(train_x_hat))[:batch_size][:nb]).to(dev)
-            ops.gather_rows(train_x, ir, xb[:nb])
-            ops.gather_rows(train_x_hat, ih, xb[nb:])
-            body = lambda cap, coef: eng.disc_step_body(xb, yb, ones, nb, cap, coef)     # noqa: E731
+            ir = torch.from_numpy(np.random.permutation(len(train_x))[:batch_size]).to(dev)
+            ih = torch.from_numpy(np.random.permutation(len(train_x_hat))[:batch_size]).to(dev)
+            ops.gather_rows(train_x, ir, xb[:n_real])
+            ops.gather_rows(train_x_hat, ih, xb[n_real:])
+            body = lambda cap, coef: eng.disc_step_body(xb, yb, ones, n_each, cap, coef)     # noqa: E731
             if graph and ops.tracing() is None:
                 eng.replay("disc", body)
             else:
                 body(False, None)
-            hist[itt:itt + 1].copy_(eng.loss)
+            hist[itt].copy_(eng.loss4)
         if losses is not None:
-            losses.extend(hist[:iterations].tolist())
+            h = hist[:iterations].cpu().double()
+            losses.extend((h[:, 0] / n_real if n_real == n_fake else h[:, 0] / n_real + h[:, 2] / n_fake).tolist())
         _, p_real = disc(test_x)
         _, p_fake = disc(test_x_hat)
     y_pred = np.squeeze(np.concatenate((p_real.cpu().numpy(), p_fake.cpu().numpy()), axis=0))

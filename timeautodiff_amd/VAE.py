@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import ops
 from .DIFF import _EmbeddingData
 from .dist import DataParallelPlan
-from .engine import VAEEngine, prec_of
+from .engine import VAEEngine, Workspace, prec_of, use_workspace
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
@@ -84,7 +84,7 @@ class DeapStack(nn.Module):
         x = self._dev_f32(x, eng)
         B, T, _ = x.shape
         if eps is None:
-            eps = torch.randn(B, T, eng.lat, device=eng.device)
+            eps = device_normals(B * T, eng.lat, eng.device).view(B, T, eng.lat)
         z, mu, lv = eng.encoder(x, self._dev_f32(eps, eng), train=False)
         return z.clone(), mu.clone(), lv.clone()
 
@@ -120,6 +120,28 @@ class DeapStack(nn.Module):
         return outputs, emb, mu_z, logvar_z
 
 
+_EPS_DRAWS = {}      # torch seed -> number of reparametrisation draws made under it in this process
+
+
+def device_normals(rows, cols, dev, row0=0, advance=True, out=None):
+    """[rows, cols] standard normals drawn on the device by the counter-based kernel (tad_sampler_noise: Philox4x32-10,
+    Box-Muller): a function of (torch.initial_seed(), the number of draws made so far under that seed, global row, column)
+    -- the reparametrisation noise of reference VAE.py:147-150 (torch.randn_like on the model's device there).  Every
+    rank of a data-parallel run makes the same sequence of draws and takes the rows it owns (``row0``): the noise of a
+    window does not depend on the sharding.  advance=False re-uses the current draw number (further rows of one draw)."""
+    seed = torch.initial_seed()
+    k = _EPS_DRAWS.get(seed, 0)
+    if advance:
+        _EPS_DRAWS[seed] = k + 1
+    elif k > 0:
+        k -= 1
+    if out is None:
+        out = torch.empty(rows, cols, dtype=torch.float32, device=dev)
+    if rows:
+        ops.sampler_noise(seed, k, row0, rows, cols, out)
+    return out
+
+
 def init_vae_state(n_bins, n_cats, n_nums, cards, input_size, hidden_size, num_layers, emb_dim, time_dim, lat_dim):
     """state_dict (CPU tensors) of a freshly constructed DeapStack under the current torch seed."""
     m = DeapStack(1, n_bins, n_cats, n_nums, list(cards), input_size, hidden_size, num_layers, emb_dim, time_dim, lat_dim)
@@ -143,9 +165,15 @@ def auto_loss(inputs, reconstruction, n_bins, n_nums, n_cats, cards):
         cols += [c.reshape(rows, -1) for c in reconstruction["cats"]]
     if "nums" in reconstruction:
         cols.append(reconstruction["nums"].reshape(rows, -1))
-    heads = torch.cat(cols, dim=1).float().contiguous()
+    # the head outputs side by side in one [rows, NH] matrix (tad_copy_2d per head)
+    heads = torch.empty(rows, sum(c.shape[1] for c in cols), dtype=torch.float32, device=dev)
+    o = 0
+    for c in cols:
+        ops.copy_2d(c.to(device=dev, dtype=torch.float32).contiguous(), heads[:, o:o + c.shape[1]])
+        o += c.shape[1]
     # the outputs already carry the mask offsets / sigmoid: evaluate the loss terms directly
-    ones = torch.ones(rows, F, device=dev)
+    ones = torch.empty(rows, F, device=dev)
+    ops.fill_(ones, 1.0)
     nb = n_bins if "bins" in reconstruction else 0
     nc = n_cats if "cats" in reconstruction else 0
     disc = torch.zeros((), device=dev)
@@ -221,7 +249,11 @@ class VAETrainer:
         self.parts_in_flat = npart <= eng.fp.SLOTS
         self.parts = eng.fp.slots(npart) if self.parts_in_flat else torch.zeros(npart, device=d)
         nb = self.plan.local_count
-        ws = eng.ws
+        # training steps and validation passes run in workspaces of the trainer's own (they work on batches of different
+        # sizes, and so do ae.encoder / ae.decoder / full_forward through the engine's default workspace): no pass
+        # re-allocates another's buffers, and captured graphs keep the addresses they were captured on
+        ws = self._ws_train = Workspace(d)
+        self._ws_eval = Workspace(d)
         self.b_inp = ws.get("batch.inp", (nb, self.T, self.F))
         self.b_tgt = ws.get("batch.tgt", (nb, self.T, self.F))
         self.b_mask = ws.get("batch.mask", (nb, self.T, self.F))
@@ -229,16 +261,13 @@ class VAETrainer:
         self.b_resp = ws.get("batch.resp", (nb, self.T, self.F)) if self.windowed else None
         self.all_indices = list(range(self.N))
         self._next_idx = None
-        # the validation pass works on a batch of another size: it gets a workspace of its own, so that neither pass
-        # re-allocates the other's buffers (and so that captured graphs keep their addresses)
-        from .engine import Workspace
-        self._ws_train, self._ws_eval = eng.ws, Workspace(d)
         # graph=True: a training step (after its draws) and a validation pass are captured as HIP graphs and replayed
         # (one graph per value of beta, which the kernels take as a launch argument).  Default: on for batches of at
         # most 512 windows in a single process; TAD_TRAIN_GRAPH=0/1 overrides.
         self._graph_opt = graph
         self._graphs = {}
         self._g_in = None
+        self._eps_bufs = {}
 
     def use_graph(self):
         import os
@@ -252,6 +281,10 @@ class VAETrainer:
         return self.B <= 512
 
     def _train_body(self, idx_d, eps_l, beta, captured=False):
+        with use_workspace(self.eng, self._ws_train):
+            self._train_body_ws(idx_d, eps_l, beta, captured)
+
+    def _train_body_ws(self, idx_d, eps_l, beta, captured):
         eng = self.eng
         ops.gather_rows(self.mask_tr, idx_d, self.b_mask)
         if self.windowed:
@@ -265,8 +298,9 @@ class VAETrainer:
             if self.b_cond is not None:
                 ops.gather_rows(self.cond_tr, idx_d, self.b_cond)
         rows = self.B * self.T
-        eng.fp.zero_grad()
-        self.parts.zero_()
+        eng.fp.zero_grad()                 # clears the loss parts with the gradients when they live in the flat buffer
+        if not self.parts_in_flat:
+            ops.zero_(self.parts)
         nc = eng.nc
         kld = self.parts[2 + max(nc, 1):]
         z, mu, lv = eng.encoder(self.b_inp, eps_l, train=True, kld_sum=kld)
@@ -275,7 +309,7 @@ class VAETrainer:
         eng.backward(beta, rows)
         upto = None if self.cond_tr is not None else eng.n_without_cond
         if captured:
-            eng.fp.adam_captured(self._g_coef, weight_decay=self.wd, upto=upto)
+            eng.fp.adam_captured(self.lr, weight_decay=self.wd, upto=upto)
         else:
             plan = self.plan
             if self.parts_in_flat:
@@ -286,16 +320,13 @@ class VAETrainer:
 
     def _eval_body(self, eps_l, lo, hi):
         eng = self.eng
-        self.parts.zero_()
+        ops.zero_(self.parts)
         nc = eng.nc
         kld = self.parts[2 + max(nc, 1):]
-        eng.ws = self._ws_eval
-        try:
+        with use_workspace(eng, self._ws_eval):
             z, mu, lv = eng.encoder(self.inp_va[lo:hi], eps_l, train=False, kld_sum=kld)
             cond = self.cond_va[lo:hi] if self.cond_va is not None else None
             eng.decoder(z, self.mask_va[lo:hi], cond, target=self.tgt_va[lo:hi], loss_parts=self.parts, train=False)
-        finally:
-            eng.ws = self._ws_train
 
     def _graph_for(self, key, build):
         """The captured graph for ``key`` (built on first use, after two eager runs on saved state)."""
@@ -313,6 +344,13 @@ class VAETrainer:
                 build(True)
             self._graphs[key] = g
         return g
+
+    def _eps_buf(self, tag, n):
+        """Persistent buffer for a pass's reparametrisation noise (no allocation per step)."""
+        key = (tag, n)
+        if key not in self._eps_bufs:
+            self._eps_bufs[key] = torch.empty(n * self.T, self.eng.lat, dtype=torch.float32, device=self.eng.device)
+        return self._eps_bufs[key]
 
     def _loss(self, rows, beta):
         """Combine the (all-reduced) partial sums on the host -> python float total."""
@@ -339,20 +377,20 @@ class VAETrainer:
             if idx_d.numel() and (int(idx_d.min()) < 0 or int(idx_d.max()) >= self.N):
                 raise IndexError("index out of range")          # the gathers below do not check
         if eps is None:
-            eps = torch.randn(self.B, self.T, eng.lat, device=d)
-        eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
+            # this rank's rows of the global batch's noise, drawn on the device
+            eps_l = device_normals((hi - lo) * self.T, eng.lat, d, row0=lo * self.T, out=self._eps_buf("train", hi - lo)).view(hi - lo, self.T, eng.lat)
+        else:
+            eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
         rows = self.B * self.T
         if self.use_graph():
             if self._g_in is None:
                 self._g_in = dict(idx=torch.zeros(hi - lo, dtype=torch.int64, device=d), eps=torch.zeros(hi - lo, self.T, eng.lat, device=d),
                                   veps=torch.zeros(self.vplan.hi - self.vplan.lo, self.T, eng.lat, device=d))
-                self._g_coef = torch.zeros(2, device=d)
-                self._g_coef_host = torch.zeros(2).pin_memory()
             gi = self._g_in
             gi["idx"].copy_(idx_d, non_blocking=True)
             gi["eps"].copy_(eps_l, non_blocking=True)
             g = self._graph_for(("train", float(beta)), lambda cap: self._train_body(gi["idx"], gi["eps"], beta, captured=cap))
-            eng.fp.adam_refresh(self.lr, self._g_coef, self._g_coef_host)
+            eng.fp.adam_before_replay()
             g.replay()
         else:
             self._train_body(idx_d, eps_l, beta)
@@ -372,10 +410,11 @@ class VAETrainer:
         """Full validation-set loss under the current weights (reference VAE.py:357-368)."""
         eng, plan = self.eng, self.vplan
         d = eng.device
-        if eps is None:
-            eps = torch.randn(self.Nv, self.T, eng.lat, device=d)
         lo, hi = plan.lo, plan.hi
-        eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
+        if eps is None:
+            eps_l = device_normals((hi - lo) * self.T, eng.lat, d, row0=lo * self.T, out=self._eps_buf("val", hi - lo)).view(hi - lo, self.T, eng.lat)
+        else:
+            eps_l = eps[lo:hi].to(device=d, dtype=torch.float32).contiguous()
         if self.use_graph() and self._g_in is not None:
             gi = self._g_in
             gi["veps"].copy_(eps_l, non_blocking=True)
@@ -391,7 +430,7 @@ class VAETrainer:
         eng = self.eng
         d = eng.device
         if eps is None:
-            eps = torch.randn(self.N, self.T, eng.lat, device=d)
+            eps = device_normals(self.N * self.T, eng.lat, d).view(self.N, self.T, eng.lat)
         inp, cond = self.inp_tr, self.cond_tr
         if self.windowed:               # the one place that needs the whole training set at once (reference VAE.py:395-402)
             cond = self.cond_tr.materialize() if self.cond_tr is not None else None
@@ -420,10 +459,13 @@ def _train(real_df, channels, hidden_size, num_layers, lr, weight_decay, n_epoch
     T, L = tr.T, eng.lat
 
     def draw(n):
-        # reference order: the CPU generator when the reference itself runs on CPU; randn_like on the device otherwise
+        # "reference": the CPU generator, in the order the reference draws when it runs on a CPU.  "device" (what the
+        # reference's randn_like does on a GPU): None -- each pass draws its rows with the counter-based kernel
         if noise_source == "reference":
             return torch.randn(n, T, L)
-        return torch.randn(n, T, L, device=d)
+        if noise_source != "device":
+            raise ValueError("noise_source must be 'reference' or 'device'")
+        return None
 
     beta = max_beta
     patience, lambd = 0, 0.7

@@ -101,6 +101,9 @@ PROTOTYPES = {
     "tad_adam_step": (_i, [_i64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
     "tad_adam_coefficients": (None, [_f, _f, _f, _i, C.POINTER(C.c_float)]),
     "tad_adam_step_dev": (_i, [_i64, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
+    "tad_adam_tick": (_i, [_f, _f, _f, _p, _p]),
+    "tad_fill_f32": (_i, [_i64, _p, _f, _p]),
+    "tad_sigmoid_f32": (_i, [_i64, _p, _p]),
     "tad_vae_reparam_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _p]),
     "tad_vae_reparam_bwd": (_i, [_i64, _p, _p, _p, _p, _f, _p, _p, _p]),
     "tad_vae_heads_loss": (_i, [_i64, _i, _i, _i, C.POINTER(C.c_int32), _p, _i64, _p, _p, _i64, _f, _f, _f, _p, _p, _p]),

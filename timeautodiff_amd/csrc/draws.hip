@@ -149,6 +149,14 @@ __global__ void add_vec_kernel(int64_t n, const float* __restrict__ a, const flo
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) out[e] = a[e] + b[e];
 }
 
+__global__ void fill_f32_kernel(int64_t n, float* __restrict__ p, float v) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
+}
+
+__global__ void sigmoid_f32_kernel(int64_t n, float* __restrict__ p) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = sigmoid_acc(p[e]);
+}
+
 inline unsigned grid_for(int64_t n) {
   int64_t g = cdiv64(n, 256);
   return (unsigned)(g < 1 ? 1 : g > 2048 ? 2048 : g);
@@ -221,6 +229,24 @@ extern "C" int tad_add_vec(int64_t n, const float* a, const float* b, float* out
   if (n == 0) return TAD_OK;
   TAD_CHECK(a && b && out, "tad_add_vec: null pointer");
   hipLaunchKernelGGL(add_vec_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, a, b, out);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_fill_f32(int64_t n, float* p, float value, tad_stream_t stream) {
+  TAD_CHECK(n >= 0, "tad_fill_f32: bad n");
+  if (n == 0) return TAD_OK;
+  TAD_CHECK(p, "tad_fill_f32: null pointer");
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, p, value);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_sigmoid_f32(int64_t n, float* p, tad_stream_t stream) {
+  TAD_CHECK(n >= 0, "tad_sigmoid_f32: bad n");
+  if (n == 0) return TAD_OK;
+  TAD_CHECK(p, "tad_sigmoid_f32: null pointer");
+  hipLaunchKernelGGL(sigmoid_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, p);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

@@ -808,6 +808,18 @@ __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __res
   }
 }
 
+// One thread: advance the step counter kept in coef[2] (int32 bits) and write the two step-dependent factors of Adam
+// to coef[0..1], in double precision like the host (tad_adam_coefficients).
+__global__ void adam_tick_kernel(float lr, float b1, float b2, float* __restrict__ coef) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int* cnt = reinterpret_cast<int*>(coef) + 2;
+  const int step = *cnt + 1;
+  *cnt = step;
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  coef[0] = (float)((double)lr / bc1);
+  coef[1] = (float)(1.0 / sqrt(bc2));
+}
+
 // out_sum[c] += sum_r dY[r,c]; out_wsum[c] += sum_r dY[r,c] * scale[r]
 __global__ void colsum_kernel(int64_t M, int64_t N, const float* __restrict__ dY, int64_t ldy,
                               const float* __restrict__ rs, int64_t rs_stride, float mul, float* __restrict__ o1,
@@ -1335,6 +1347,13 @@ extern "C" int tad_adam_step_dev(int64_t n, float* p, const float* g, float* m, 
   if (n == 0) return TAD_OK;
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, EW_STREAM, n, p, g, m, v, beta1, beta2, eps, weight_decay,
                      0.f, 0.f, coef2);
+  TAD_LAUNCH_CHECK();
+  return TAD_OK;
+}
+
+extern "C" int tad_adam_tick(float lr, float beta1, float beta2, float* coef4, tad_stream_t stream) {
+  TAD_CHECK(coef4 && (reinterpret_cast<uintptr_t>(coef4) & 3) == 0, "tad_adam_tick: bad coef4");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, EW_STREAM, lr, beta1, beta2, coef4);
   TAD_LAUNCH_CHECK();
   return TAD_OK;
 }

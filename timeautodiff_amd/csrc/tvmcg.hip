@@ -179,6 +179,15 @@ extern "C" int tad_metadata_noise_static(int64_t rows, int64_t F, int n_cols, co
                                          tad_stream_t stream) {
   TAD_CHECK(n_cols >= 0 && n_cols <= TV_MAX_COLS, "tad_metadata_noise_static: %d selected columns exceed the static scratch (at most %d)",
             n_cols, TV_MAX_COLS);
+  // The scratch array that is used is the CURRENT device's copy, and so is the device the kernels are launched on: a
+  // stream that belongs to another GPU is rejected here (its kernels could not reach this GPU's array).
+  if (stream) {
+    hipDevice_t sdev = -1;
+    int cur = -1;
+    const hipError_t e1 = hipStreamGetDevice((hipStream_t)stream, &sdev), e2 = hipGetDevice(&cur);
+    TAD_CHECK(e1 == hipSuccess && e2 == hipSuccess, "tad_metadata_noise_static: cannot tell the stream's device: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    TAD_CHECK((int)sdev == cur, "tad_metadata_noise_static: the stream belongs to device %d, the current device is %d (make the stream's device current)", (int)sdev, cur);
+  }
   double* stats = nullptr;
   if (int rc = scratch_address(&stats)) return rc;
   return metadata_noise_launch("tad_metadata_noise_static", rows, F, n_cols, cols, cond, ld, noise, level, stats, out, ldo, stream);

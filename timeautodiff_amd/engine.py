@@ -190,21 +190,32 @@ class FlatParams:
             torch.cuda.current_stream().wait_event(self._join_ev)
             self._side_busy = False
 
-    def adam_captured(self, coef2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, upto=None):
-        """The launch of ``adam`` for a HIP-graph capture: the step-dependent factors are read from the device tensor
-        ``coef2`` (see ``adam_refresh``); the step counter and the parameter version are advanced per replay by
-        ``adam_refresh``, not here."""
-        n = self.n_active if upto is None else min(int(upto), self.n_active)
-        ops.adam_step_dev(self.flat[:n], self.gflat[:n], self.m[:n], self.v[:n], betas[0], betas[1], eps, weight_decay, coef2)
+    def adam_state(self):
+        """Device-side optimizer state of captured steps: float32[4] = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step),
+        the step counter (int32 bits), unused}; ``_dev_step`` mirrors the counter on the host."""
+        if getattr(self, "_coef", None) is None:
+            self._coef = torch.zeros(4, dtype=torch.float32, device=self.device)
+            self._dev_step = 0
+        return self._coef
 
-    def adam_refresh(self, lr, coef2, host2=None, betas=(0.9, 0.999)):
-        """Before a replay of a captured step: advance the step counter and put its bias-correction factors where
-        the captured Adam launch reads them."""
+    def adam_captured(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, upto=None):
+        """The launches of ``adam`` for a HIP-graph capture: a single-thread launch advances the step counter kept on the
+        device and refreshes the two step-dependent factors, the Adam launch reads them from there -- a replay needs no
+        host-to-device copy (``adam_replayed`` does the host-side bookkeeping)."""
+        coef = self.adam_state()
+        n = self.n_active if upto is None else min(int(upto), self.n_active)
+        ops.adam_tick(coef, lr, betas[0], betas[1])
+        ops.adam_step_dev(self.flat[:n], self.gflat[:n], self.m[:n], self.v[:n], betas[0], betas[1], eps, weight_decay, coef)
+
+    def adam_before_replay(self):
+        """Before a replay of a captured step: the device's step counter must equal the host's (eager steps in between,
+        or a restored state, move the host's only) -- re-seeded with one small copy when it does not."""
+        coef = self.adam_state()
+        if self._dev_step != self.step:
+            coef[2:3].view(torch.int32).copy_(torch.tensor([self.step], dtype=torch.int32), non_blocking=False)
+            self._dev_step = self.step
         self.step += 1
-        c0, c1 = ops.adam_coefficients(lr, betas[0], betas[1], self.step)
-        # a fresh pageable tensor per step: the runtime stages it at the call, so the next step's values cannot
-        # overtake a copy that is still queued (a reused pinned buffer would be rewritten under it)
-        coef2.copy_(torch.tensor([c0, c1], dtype=torch.float32), non_blocking=True)
+        self._dev_step += 1
         self.version += 1
 
     def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, upto=None):
@@ -314,6 +325,23 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
 
+class use_workspace:
+    """``with use_workspace(engine, ws):`` -- the engine's launch sequences work in ``ws`` inside the block.  A trainer
+    runs its steps in a workspace of its own: a captured HIP graph holds the addresses of the buffers it was captured
+    on, and the engine's default workspace is re-sized by whoever calls the module surface (model(...), ae.encoder,
+    sample) with another batch size between two steps."""
+
+    def __init__(self, eng, ws):
+        self.eng, self.ws = eng, ws
+
+    def __enter__(self):
+        self.prev, self.eng.ws = self.eng.ws, self.ws
+        return self.ws
+
+    def __exit__(self, *exc):
+        self.eng.ws = self.prev
+
+
 # ---------------------------------------------------------------------------
 class RnnStack:
     """Multi-layer LSTM/GRU with ``ndir`` directions ("bidir": every layer reads the
@@ -420,13 +448,14 @@ class RnnStack:
 
     def _xproj(self, layer, x, w_gl, bias_gl, xproj):
         """Input-side pre-activations from the rows ``w_gl`` of the layer's gate-interleaved weight image."""
+        uf = self.G / 4.0           # a GRU's fourth slot is structural padding (zero weights)
         if x.dtype == torch.bfloat16:
             assert self.mm16[layer]
-            ops.mm16_nt(x, w_gl, bias_gl, xproj)
+            ops.mm16_nt(x, w_gl, bias_gl, xproj, useful=uf)
         elif self.store[layer] == torch.bfloat16:
-            ops.linear_fwd_b16(x, w_gl[:xproj.shape[1], :x.shape[1]], bias_gl, xproj)
+            ops.linear_fwd_b16(x, w_gl[:xproj.shape[1], :x.shape[1]], bias_gl, xproj, useful=uf)
         else:
-            ops.linear_fwd(self.prec, x, w_gl, bias_gl, xproj)
+            ops.linear_fwd(self.prec, x, w_gl, bias_gl, xproj, useful=uf)
 
     def forward(self, x, B, T, ws: Workspace, tag, train, last16=None):
         """x [B*T, in_dim] float32, or bfloat16 where layer 0 takes the bf16-stored-operand products.  Returns the
@@ -584,7 +613,7 @@ class RnnStack:
                 padded = shared and self.in_p(layer) != in_l
                 wl = self.w_gl[layer][:, :self.in_p(layer)]
                 if layer == 0 and dx16 is not None and sdt == torch.bfloat16 and shared and not padded:
-                    ops.linear_bwd_data_b16o(dg, wl, dx16, relu_of16=relu_of)
+                    ops.linear_bwd_data_b16o(dg, wl, dx16, relu_of16=relu_of, useful=G / 4.0)
                     dout = dx16
                     continue
                 dx = ws.get(f"{tag}.dx{layer}", (BT, (self.in_p(layer) if padded else in_l) if shared else nd * H))
@@ -592,8 +621,8 @@ class RnnStack:
                     relu_of, mask16 = None, relu_of            # the mask is applied with the rounding below
                 ro = relu_of if layer == 0 else None
                 assert not (padded and ro is not None), "a ReLU mask on a padded layer input is not supported"
-                bwd_data = (lambda dy, w, o, r=None: ops.linear_bwd_data_b16(dy, w, o, relu_of=r)) if sdt == torch.bfloat16 else \
-                    (lambda dy, w, o, r=None: ops.linear_bwd_data(prec, dy, w, o, relu_of=r))
+                bwd_data = (lambda dy, w, o, r=None: ops.linear_bwd_data_b16(dy, w, o, relu_of=r, useful=G / 4.0)) if sdt == torch.bfloat16 else \
+                    (lambda dy, w, o, r=None: ops.linear_bwd_data(prec, dy, w, o, relu_of=r, useful=G / 4.0))
                 if shared:
                     bwd_data(dg, wl, dx, ro)
                 else:

@@ -114,25 +114,36 @@ class LaunchTrace:
         global _TRACE
         _TRACE = self._prev
 
-    def summary(self):
-        """{(entry point, integer args): [calls, total_ms, algorithmic FLOPs per call, algorithmic HBM bytes per call]}."""
+    def _aggregate(self, group):
+        """{group(record): {key: [calls, total_ms, mean algorithmic FLOPs per call, mean algorithmic HBM bytes per call,
+        mean issued FLOPs per call]}}: every record adds its OWN cost (calls that share a key -- the same entry point
+        with the same leading integer arguments -- may still differ in the work they do: the weight-gradient launches
+        of the four recurrent layers of a step do)."""
         torch.cuda.synchronize()
         out = {}
-        for key, _, e0, e1, cost in self.records:
-            ent = out.setdefault(key, [0, 0.0, cost[0], cost[1]])
+        for rec in self.records:
+            key, _, e0, e1, cost = rec
+            ent = out.setdefault(group(rec), {}).setdefault(key, [0, 0.0, 0.0, 0.0, 0.0])
             ent[0] += 1
             ent[1] += e0.elapsed_time(e1)
+            ent[2] += cost[0]
+            ent[3] += cost[1]
+            ent[4] += cost[2] if len(cost) > 2 else cost[0]
+        for keys in out.values():
+            for ent in keys.values():
+                ent[2] /= ent[0]
+                ent[3] /= ent[0]
+                ent[4] /= ent[0]
         return out
 
+    def summary(self):
+        """{(entry point, integer args): [calls, total_ms, algorithmic FLOPs per call, algorithmic HBM bytes per call,
+        issued FLOPs per call] (means over the calls of the key)}."""
+        return self._aggregate(lambda rec: None).get(None, {})
+
     def summary_by_kernel(self):
-        """{device kernel name (entry point name if the call names no kernel): {key: [calls, total_ms, flops, bytes]}}."""
-        torch.cuda.synchronize()
-        out = {}
-        for key, kern, e0, e1, cost in self.records:
-            ent = out.setdefault(kern or key[0], {}).setdefault(key, [0, 0.0, cost[0], cost[1]])
-            ent[0] += 1
-            ent[1] += e0.elapsed_time(e1)
-        return out
+        """{device kernel name (entry point name if the call names no kernel): {key: [calls, total_ms, flops, bytes, issued flops]}}."""
+        return self._aggregate(lambda rec: rec[1] or rec[0][0])
 
 
 _TRACE = None
@@ -145,7 +156,8 @@ def tracing():
 
 def _call(name, *args, cost=(0.0, 0.0)):
     """Calls a C-ABI entry point.  ``cost`` = (algorithmic FLOPs, algorithmic HBM bytes: every operand and result
-    once at its storage width) of the call, recorded by an installed LaunchTrace."""
+    once at its storage width[, FLOPs the kernel issues, padding of its tiles included]) of the call, recorded by an
+    installed LaunchTrace."""
     lib = _lib.load()
     if _TRACE is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -162,7 +174,13 @@ def _call(name, *args, cost=(0.0, 0.0)):
 
 
 # ------------------------------------------------------------------ linear family
-def linear_fwd(prec, x, w, bias, y, act=ACT_NONE, accumulate=False, bias2=None, residual=None):
+def _cost(flops, nbytes, useful):
+    """(algorithmic FLOPs, bytes, issued FLOPs): ``useful`` < 1 where a share of the operand is structural padding (the
+    spare fourth slot of a GRU's gate-interleaved tensors meets zero weights: 3/4 of the issued product is the model's)."""
+    return (flops * useful, nbytes, flops)
+
+
+def linear_fwd(prec, x, w, bias, y, act=ACT_NONE, accumulate=False, bias2=None, residual=None, useful=1.0):
     """y = act(x w^T + bias + bias2 + residual); accumulate=True uses y itself as the residual."""
     xp, M, K, ldx = as2d(x)
     wp, N, Kw, ldw = as2d(w)
@@ -176,10 +194,10 @@ def linear_fwd(prec, x, w, bias, y, act=ACT_NONE, accumulate=False, bias2=None, 
         rp, Mr, Nr, ldr = as2d(residual)
         assert Mr == M and Nr == N
     _call("tad_linear_fwd", prec, M, N, K, xp, ldx, wp, ldw, _ptr(bias), _ptr(bias2), rp, ldr, yp, ldy, act, _stream(),
-          cost=(2.0 * M * N * K, 4.0 * (M * K + N * K + M * N + (M * N if rp else 0))))
+          cost=_cost(2.0 * M * N * K, 4.0 * (M * K + N * K + M * N + (M * N if rp else 0)), useful))
 
 
-def linear_bwd_data(prec, dy, w, dx, relu_of=None, accumulate=False):
+def linear_bwd_data(prec, dy, w, dx, relu_of=None, accumulate=False, useful=1.0):
     dyp, M, N, ldy = as2d(dy)
     wp, Nw, K, ldw = as2d(w)
     dxp, Mx, Kx, ldx = as2d(dx)
@@ -189,7 +207,7 @@ def linear_bwd_data(prec, dy, w, dx, relu_of=None, accumulate=False):
         rp, Mr, Kr, ldr = as2d(relu_of)
         assert Mr == M and Kr == K
     _call("tad_linear_bwd_data", prec, M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream(),
-          cost=(2.0 * M * N * K, 4.0 * (M * N + N * K + M * K * (1 + bool(rp) + bool(accumulate)))))
+          cost=_cost(2.0 * M * N * K, 4.0 * (M * N + N * K + M * K * (1 + bool(rp) + bool(accumulate))), useful))
 
 
 def _gate_map(gate_map):
@@ -216,7 +234,7 @@ def linear_bwd_weight(prec, dy, x, dw, db=None, db2=None, T=0, tshift=0, gate_ma
     assert M == Mx and n_out == Nw and K == Kw, (dy.shape, x.shape, dw.shape, gate_map)
     for b in (db, db2):
         assert b is None or (b.is_contiguous() and b.numel() == n_out), (n_out, None if b is None else b.shape)
-    cost = (2.0 * M * N * K, dy.element_size() * M * N + 4.0 * M * K + 4.0 * n_out * K)
+    cost = (2.0 * M * n_out * K, dy.element_size() * M * N + 4.0 * M * K + 4.0 * n_out * K, 2.0 * M * N * K)
     if b16:
         assert prec == BF16
         _call("tad_linear_bwd_weight_b16", M, N, K, dyp, ldy, xp, ldx, dwp, ldw, _ptr(db), _ptr(db2), T, tshift,
@@ -226,17 +244,17 @@ def linear_bwd_weight(prec, dy, x, dw, db=None, db2=None, T=0, tshift=0, gate_ma
               _gate_map(gate_map), _stream(), cost=cost)
 
 
-def linear_fwd_b16(x, w16, bias, y, act=ACT_NONE):
+def linear_fwd_b16(x, w16, bias, y, act=ACT_NONE, useful=1.0):
     """y = act(x w16^T + bias): x fp32, w16 bfloat16 [N,K], y float32 or bfloat16 (bf16 matrix cores)."""
     xp, M, K, ldx = as2d(x)
     wp, N, Kw, ldw = as2d(w16, torch.bfloat16)
     yp, My, Ny, ldy = as2d(y, y.dtype)
     assert K == Kw and M == My and N == Ny, (x.shape, w16.shape, y.shape)
     _call("tad_linear_fwd_b16", M, N, K, xp, ldx, wp, ldw, _ptr(bias), yp, BF16 if y.dtype == torch.bfloat16 else F32, ldy,
-          act, _stream(), cost=(2.0 * M * N * K, 4.0 * M * K + 2.0 * N * K + y.element_size() * M * N))
+          act, _stream(), cost=_cost(2.0 * M * N * K, 4.0 * M * K + 2.0 * N * K + y.element_size() * M * N, useful))
 
 
-def linear_bwd_data_b16(dy16, w16, dx, relu_of=None, accumulate=False):
+def linear_bwd_data_b16(dy16, w16, dx, relu_of=None, accumulate=False, useful=1.0):
     """dx = dy16 w16 (+ dx), masked where relu_of <= 0: dy16 bfloat16 [M,N], w16 bfloat16 [N,K], dx fp32."""
     dyp, M, N, ldy = as2d(dy16, torch.bfloat16)
     wp, Nw, K, ldw = as2d(w16, torch.bfloat16)
@@ -247,10 +265,10 @@ def linear_bwd_data_b16(dy16, w16, dx, relu_of=None, accumulate=False):
         rp, Mr, Kr, ldr = as2d(relu_of)
         assert Mr == M and Kr == K
     _call("tad_linear_bwd_data_b16", M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, int(accumulate), _stream(),
-          cost=(2.0 * M * N * K, 2.0 * (M * N + N * K) + 4.0 * M * K * (1 + bool(rp) + bool(accumulate))))
+          cost=_cost(2.0 * M * N * K, 2.0 * (M * N + N * K) + 4.0 * M * K * (1 + bool(rp) + bool(accumulate)), useful))
 
 
-def linear_bwd_data_b16o(dy16, w16, dx16, relu_of16=None):
+def linear_bwd_data_b16o(dy16, w16, dx16, relu_of16=None, useful=1.0):
     """dx16 = dy16 w16, masked where relu_of16 <= 0: every operand bfloat16 (a dx that only matrix products read)."""
     b16 = torch.bfloat16
     dyp, M, N, ldy = as2d(dy16, b16)
@@ -262,7 +280,7 @@ def linear_bwd_data_b16o(dy16, w16, dx16, relu_of16=None):
         rp, Mr, Kr, ldr = as2d(relu_of16, b16)
         assert Mr == M and Kr == K
     _call("tad_linear_bwd_data_b16o", M, N, K, dyp, ldy, wp, ldw, dxp, ldx, rp, ldr, _stream(),
-          cost=(2.0 * M * N * K, 2.0 * (M * N + N * K) + 2.0 * M * K * (1 + bool(rp))))
+          cost=_cost(2.0 * M * N * K, 2.0 * (M * N + N * K) + 2.0 * M * K * (1 + bool(rp)), useful))
 
 
 def _dt(t):
@@ -280,7 +298,7 @@ def w16_image(n, k, device):
     return torch.zeros(-(-n // 64) * 64, -(-k // 128) * 128, dtype=torch.bfloat16, device=device)
 
 
-def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=None):
+def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=None, useful=1.0):
     """c = act(a16 w16[:N, :K]^T + bias + residual), zeroed where relu_of <= 0 (act=ACT_DSILU: multiplied by silu'(relu_of) instead): a16 [M,K] bfloat16, w16 a padded
     bfloat16 weight image (``w16_image``: rows >= N rounded up to 64, columns K rounded up to 128, zeros beyond K),
     c [M,N] float32 or bfloat16, residual / relu_of float32 or bfloat16 [M,N]; z_out (bfloat16) receives the value
@@ -304,12 +322,14 @@ def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=
         assert Mz == M and Nz == N
     _call("tad_mm16_nt", M, N, K, ap, lda, wp, ldw, _ptr(bias), rp or None, rdt, ldr, up or None, udt, ldu, cp, _dt(c), ldc,
           zp or None, ldz, act, _stream(),
-          cost=(2.0 * M * N * K, 2.0 * (M * K + N * K) + c.element_size() * M * N
-                + (residual.element_size() * M * N if residual is not None else 0)
-                + (relu_of.element_size() * M * N if relu_of is not None else 0) + (z_out.element_size() * M * N if z_out is not None else 0)))
+          cost=_cost(2.0 * M * N * K, 2.0 * (M * K + N * K) + c.element_size() * M * N
+                     + (residual.element_size() * M * N if residual is not None else 0)
+                     + (relu_of.element_size() * M * N if relu_of is not None else 0)
+                     + (z_out.element_size() * M * N if z_out is not None else 0), useful))
 
 
 TN_MAXJOBS = 12
+TN_TILE_A = 256          # columns of A per workgroup tile of tad_mm16_tn (B is multiplied in 32-column blocks)
 
 
 def mm16_tn(a16, jobs, T=0):
@@ -321,7 +341,7 @@ def mm16_tn(a16, jobs, T=0):
     columns of the product (b's extra columns are zero padding)."""
     ap, M, Na, lda = as2d(a16, torch.bfloat16) if a16 is not None else (None, None, 0, 0)
     arr = (_lib.TnJob * len(jobs))()
-    flops = bytes_ = 0.0
+    flops = bytes_ = issued = 0.0
     own_a = set()
     for k, j in enumerate(jobs):
         b, c = j["b"], j["c"]
@@ -346,11 +366,14 @@ def mm16_tn(a16, jobs, T=0):
             assert d is None or (d.is_contiguous() and d.numel() == n_out)
         g6 = (C.c_int32 * 6)(*( (gm[0], gm[1], *gm[2]) if gm is not None else (0, 0, 0, 0, 0, 0)))
         arr[k] = _lib.TnJob(bp, ldb, nb, j.get("shift", 0), cp, ldc, _ptr(j.get("db")), _ptr(j.get("db2")), a0, na, g6, jap, jlda)
-        flops += 2.0 * M * na * nb
-        bytes_ += 2.0 * M * nb + 4.0 * n_out * nb
+        # algorithmic: the rows and columns of C the product fills (a GRU's spare slot and B's zero padding produce
+        # nothing); issued: what the kernel multiplies, its tile padding included
+        flops += 2.0 * M * n_out * nbc
+        issued += 2.0 * M * (-(-na // TN_TILE_A) * TN_TILE_A) * (-(-nb // 32) * 32)
+        bytes_ += 2.0 * M * nb + 4.0 * n_out * nbc
     if a16 is not None:
         bytes_ += 2.0 * M * Na
-    _call("tad_mm16_tn", M, T, ap, lda, len(jobs), arr, _stream(), cost=(flops, bytes_))
+    _call("tad_mm16_tn", M, T, ap, lda, len(jobs), arr, _stream(), cost=(flops, bytes_, issued))
 
 
 def cvt_bf16(src, dst16, relu_of=None):
@@ -644,6 +667,22 @@ def zero_(t):
     return t
 
 
+def fill_(t, value):
+    """t[...] = value for a contiguous float32 tensor (tad_fill_f32)."""
+    assert t.is_contiguous() and t.dtype == torch.float32
+    if t.numel():
+        _call("tad_fill_f32", t.numel(), _ptr(t), float(value), _stream(), cost=(0.0, 4.0 * t.numel()))
+    return t
+
+
+def sigmoid_(t):
+    """t = 1 / (1 + exp(-t)) in place for a contiguous float32 tensor (tad_sigmoid_f32; torch.sigmoid's fp32 formula)."""
+    assert t.is_contiguous() and t.dtype == torch.float32
+    if t.numel():
+        _call("tad_sigmoid_f32", t.numel(), _ptr(t), _stream(), cost=(0.0, 8.0 * t.numel()))
+    return t
+
+
 def copy_2d(src, dst):
     """dst[:, :cols] = src (float32, unit column stride)."""
     sp, rows, cols, lds_ = as2d(src)
@@ -721,10 +760,18 @@ def adam_coefficients(lr, beta1, beta2, step):
     return float(out[0]), float(out[1])
 
 
+def adam_tick(coef4, lr, beta1, beta2):
+    """Advance the device-side step counter of a captured optimizer step (coef4[2], an int32 stored in the float32
+    buffer) and refresh the two factors tad_adam_step_dev reads from coef4[0:2] -- one single-thread launch that a HIP
+    graph captures in front of the Adam launch, so that a replay needs no host-to-device copy."""
+    assert coef4.numel() >= 4 and coef4.dtype == torch.float32 and coef4.is_contiguous()
+    _call("tad_adam_tick", float(lr), float(beta1), float(beta2), _ptr(coef4), _stream())
+
+
 def adam_step_dev(p, g, m, v, beta1, beta2, eps, weight_decay, coef2):
-    """Adam step whose step-dependent factors come from the 2-element device tensor coef2 (graph replays)."""
+    """Adam step whose step-dependent factors come from the device tensor coef2 ([0:2]; graph replays)."""
     n = p.numel()
-    assert g.numel() == n and m.numel() == n and v.numel() == n and coef2.numel() == 2 and coef2.dtype == torch.float32
+    assert g.numel() == n and m.numel() == n and v.numel() == n and coef2.numel() >= 2 and coef2.dtype == torch.float32
     _call("tad_adam_step_dev", n, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), float(beta1), float(beta2), float(eps),
           float(weight_decay), _ptr(coef2), _stream())
 
