@@ -1,4 +1,4 @@
-"""One rank of the data-parallel rehearsal on a single GPU (started by test_gpu_dp.py as a fresh process):
+"""One rank of the data-parallel rehearsal on a single GPU (started by test_y_gpu_dp.py as a fresh process):
 3 steps of DiffusionTrainer and of VAETrainer (+ eval_loss) and one DIFF.sample on a batch that the ranks do not
 divide evenly, with a gloo group holding device tensors.  Rank 0 writes what the test compares.
 usage: python dp_gpu_worker.py RANK WORLD PORT OUT.npz"""
@@ -15,6 +15,8 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    import faulthandler
+    faulthandler.dump_traceback_later(120, exit=True)      # a rank that hangs says where, and ends
     if world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     pg = True if world > 1 else None

@@ -125,3 +125,38 @@ def test_vae_trainer_on_windowed_tables_equals_stacked_windows():
     assert float((runs[0][2] - runs[1][2]).norm() / runs[0][2].norm()) < 1e-3
     with pytest.raises(IndexError):
         tr.train_step(0.1, idx=list(range(N - 7, N + 1)))
+
+
+def test_launch_trace_bills_every_launch_its_own_work_and_adds_up_to_the_model():
+    """The per-kernel figures of the bench come from ops.LaunchTrace: every launch is billed its own algorithmic FLOPs
+    (the weight-gradient launches of a step's four recurrent layers share an entry point and leading arguments but not
+    their work), a GRU's spare gate slot and tile padding count as issued, not as algorithmic work, and the launches of
+    one training step add up to the model's 3 x forward FLOPs (a little less: no gradient is taken with respect to the
+    model's inputs)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from timeautodiff_amd import ops
+    from timeautodiff_amd.DIFF import BiRNN_score, DiffusionTrainer
+    dev = torch.device("cuda:0")
+    B = 512
+    torch.manual_seed(3)
+    latent, time_info, cond = bench.synth(2 * B, 3, dev)
+    model = BiRNN_score(bench.K, bench.F, bench.H, 2, 100, 8, bench.E, 0, 1, 27, [8])
+    tr = DiffusionTrainer(model, latent, time_info, cond, batch_size=B, dtype="bf16", draws="device", dev=dev)
+    for _ in range(2):
+        tr.step()
+    with ops.LaunchTrace() as t:
+        tr.step()
+    recs = [r for r in t.records if r[0][0] == "tad_mm16_tn"]
+    costs = sorted(r[4][0] for r in recs)
+    assert len(recs) == 5 and len(set(costs)) >= 4, costs            # LSTM l0 / l1, GRU l0 / l1, the thin products
+    by = t.summary_by_kernel()
+    tn = by["mm16_tn_kernel"]
+    assert abs(sum(c * fl for c, _, fl, _, _ in tn.values()) - sum(costs)) < 1e-6 * sum(costs)
+    assert all(iss >= fl for c, _, fl, _, iss in tn.values())
+    total = sum(c * fl for calls in by.values() for c, _, fl, _, _ in calls.values())
+    model_flops = 3 * 2 * bench.fwd_macs_per_sample() * B
+    print("traced / model FLOPs per step: %.4f" % (total / model_flops))
+    assert 0.90 < total / model_flops < 1.005

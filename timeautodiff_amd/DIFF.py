@@ -360,6 +360,20 @@ class DiffusionTrainer:
         d = eng.device
         dr = draw if draw is not None else self.draw()
         lo, hi = plan.lo, plan.hi
+        fp = eng.fp
+        pending = []
+        if hi == lo:
+            # an empty shard (more ranks than windows in the global batch): nothing to compute, but this rank still
+            # contributes zeros to both buckets' reductions, in the order every other rank issues them
+            fp.zero_grad()
+            pending.append(plan.all_reduce_async(fp.gflat[:eng.first_bucket_end]))
+            pending.append(plan.all_reduce_async(fp.gflat[eng.first_bucket_end:fp.n_active + 1]))
+            for w in pending:
+                w.wait()
+            fp.adam(self.lr)
+            if loss_out is not None:
+                torch.div(self.loss_sum, float(self.B * self.T * self.K), out=loss_out)
+            return
         idx = dr["idx"][lo:hi].to(d, non_blocking=True)
         t = dr["t"][lo:hi].to(d, dtype=torch.float32, non_blocking=True).contiguous()
         i_idx = dr["i"][lo:hi].to(d, dtype=torch.int32, non_blocking=True).contiguous()
@@ -367,9 +381,7 @@ class DiffusionTrainer:
         ops.gather_rows(self.x, idx, self.bx)
         _gather(self.time_info, idx, self.bt)
         _gather(self.cond, idx, self.bc)
-        eng.fp.zero_grad()                  # the loss slot with it
-        fp = eng.fp
-        pending = []
+        fp.zero_grad()                  # the loss slot with it
         if plan.world > 1:
             # two buckets: the head of the flat buffer (input_proj .. fc) is complete once the backward has passed
             # `proj`; its all-reduce starts there, ordered after the gradient stream's launches so far, and runs
@@ -490,8 +502,9 @@ def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, 
 
     def prep(a, last):
         return a[lo:hi].to(device=d, dtype=torch.float32).reshape(nb, T, last).contiguous()
-    eng.sample_loop(x, prep(t, 1), prep(time_info, time_info.shape[-1]), prep(cond, cond.shape[-1]), z_all,
-                    betas, alphas, keep=keep, streams=streams, graph=graph)
+    if nb > 0:          # (a rank whose slice of the batch is empty only takes part in the gather below)
+        eng.sample_loop(x, prep(t, 1), prep(time_info, time_info.shape[-1]), prep(cond, cond.shape[-1]), z_all,
+                        betas, alphas, keep=keep, streams=streams, graph=graph)
     if plan.world > 1 and not local_only:
         return plan.all_gather_cat(x)
     return x

@@ -286,6 +286,17 @@ class VAETrainer:
 
     def _train_body_ws(self, idx_d, eps_l, beta, captured):
         eng = self.eng
+        if idx_d.numel() == 0:
+            # an empty shard of the global batch: zeros into the reduction, then the same optimizer step as every rank
+            eng.fp.zero_grad()
+            if not self.parts_in_flat:
+                ops.zero_(self.parts)
+            if self.parts_in_flat:
+                self.plan.all_reduce(eng.fp.gflat[:eng.fp.n_active + self.parts.numel()])
+            else:
+                self.plan.all_reduce(eng.fp.gflat[:eng.fp.n_active], self.parts)
+            eng.fp.adam(self.lr, weight_decay=self.wd, upto=None if self.cond_tr is not None else eng.n_without_cond)
+            return
         ops.gather_rows(self.mask_tr, idx_d, self.b_mask)
         if self.windowed:
             self.resp_tr.gather_unchecked(idx_d, self.b_resp)          # indices come from a draw over range(N)
@@ -323,6 +334,8 @@ class VAETrainer:
         ops.zero_(self.parts)
         nc = eng.nc
         kld = self.parts[2 + max(nc, 1):]
+        if hi == lo:
+            return                              # an empty shard of the validation set adds nothing to the sums
         with use_workspace(eng, self._ws_eval):
             z, mu, lv = eng.encoder(self.inp_va[lo:hi], eps_l, train=False, kld_sum=kld)
             cond = self.cond_va[lo:hi] if self.cond_va is not None else None

@@ -75,9 +75,12 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 
 #ifdef MM16_STAMPS
 __device__ unsigned long long g_mm16_stamps[8];
+__device__ unsigned long long g_tn_stamps[32];
+#define TSTAMP(i) asm volatile("s_memtime %0" : "=s"(ts_[i]) :: "memory")
 #define MSTAMP(var) __builtin_amdgcn_sched_barrier(0); unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
 #else
 #define MSTAMP(var)
+#define TSTAMP(i)
 #endif
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -427,6 +430,11 @@ __global__ __launch_bounds__(64 * NT_NW, KS16 <= 36 ? 2 : 1) void mm16_nt_kernel
 
 #ifdef MM16_STAMPS
 }  // namespace
+extern "C" int tad_dbg_tn_stamps(unsigned long long* out32, int reset) {
+  if (out32) hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_tn_stamps), 256);
+  if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_tn_stamps), z, 256); }
+  return 0;
+}
 extern "C" int tad_dbg_mm16_stamps(unsigned long long* out8, int reset) {
   if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mm16_stamps), 64);
   if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_mm16_stamps), z, 64); }
@@ -474,13 +482,13 @@ int launch_nt(NtParams& p, hipStream_t s) {
 // Tile: 256 columns of A x 256 columns of B per workgroup of 8 waves, 4 along A x 2 along B: a wave owns 64 x 128 of
 // the tile (2 x 4 MFMA blocks) and skips the 32-column blocks of B beyond the operand.  For the recurrent layers
 // (B = x or h_{t-1}, at most 256 wide per tile) a column of the gate gradients is fetched into LDS by one workgroup
-// only.  Stage = 32 reduction rows: A image [32][256] + B image [32][256] bf16 (32 KiB); 4 stages, three in flight.
+// only.  Stage = 32 reduction rows: A image [32][256] + B image [32][256] bf16 (32 KiB); 5 stages, three to four in flight.
 constexpr int TN_MAXJOBS = 12;
 constexpr int TN_BK = 32;                      // reduction rows per stage
 constexpr int TN_TA = 256, TN_TB = 256;        // tile: columns of A, columns of B
 constexpr int TN_IMG = TN_BK * 512;            // bytes of one image: [32 rows][256 columns] bf16
 constexpr int TN_STAGE = 2 * TN_IMG;
-constexpr int TN_ST = 4;
+constexpr int TN_ST = 5;
 
 struct TnJob {
   const bf16_t* A; int64_t lda;                            // this job's A operand [M, lda]
@@ -579,32 +587,40 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
     ca[j] = a_c0 + 8 * fch; if (ca[j] > a_end - 8) ca[j] = a_end - 8;     // beyond the range: any readable column (feeds rows / columns nobody stores)
     cb[j] = b_c0 + 8 * fch; if (cb[j] > b_end - 8) cb[j] = b_end - 8;
   }
-  const unsigned char* const abase = reinterpret_cast<const unsigned char*>(J.A);
-  const unsigned char* const bbase = reinterpret_cast<const unsigned char*>(J.B);
+  // Source addresses: one 64-bit pointer per lane and piece, advanced by a slab per issue (the slabs are issued in
+  // order); everything the loop needs from the job lives in registers from here on (a field of p.job[ji] read inside
+  // the loop is a scalar load from the kernel arguments, and the wait for it also waits for every LDS read in flight).
   const int T = p.T, shift = J.shift;
-  int tpos[2];                                                      // time position of this lane's rows (only with a shift)
+  const int lda = __builtin_amdgcn_readfirstlane((int)J.lda), ldb = __builtin_amdgcn_readfirstlane((int)J.ldb);
+  const int nrows = (int)(m_end - m_beg);                           // rows of this split
+  const int64_t step_a = (int64_t)TN_BK * lda * 2, step_b = (int64_t)TN_BK * ldb * 2;
+  uint64_t pa[2], pb[2];
+  int rrow[2], tpos[2];                                             // row inside the split / time position of the lane's pieces
 #pragma unroll
-  for (int j = 0; j < 2; ++j) tpos[j] = T > 0 ? (int)((m_beg + 2 * (2 * wave + j) + fsub) % T) : 0;
+  for (int j = 0; j < 2; ++j) {
+    rrow[j] = 2 * (2 * wave + j) + fsub;
+    const int64_t m = m_beg + rrow[j];
+    pa[j] = (uint64_t)(uintptr_t)J.A + (uint64_t)(2 * (m * lda + ca[j]));
+    pb[j] = (uint64_t)(uintptr_t)J.B + (uint64_t)(2 * ((m + shift) * ldb + cb[j]));      // only dereferenced for rows inside their window
+    tpos[j] = T > 0 ? (int)(m % T) : 0;
+  }
   const int tstep = T > 0 ? TN_BK % T : 0;
-  auto issue = [&](int q, int stage) {
+  const uint64_t zero64 = (uint64_t)(uintptr_t)zero;
+  // the wave's four pieces of the next slab (two row pairs of each image); beyond the split's last row -- and beyond its
+  // last slab, where the loads only keep the counts uniform -- they read the zero page
+  auto issue_half = [&](int stage, int j) {
     unsigned char* st = smem + stage * TN_STAGE + wave * 2048;
-    // beyond the end of the range the loads only keep the counts uniform: they read the zero page (the time
-    // positions below are those of real slabs only, so no row may be derived from them there)
-    const bool live = q < nslab;
-    const int64_t m0 = m_beg + (int64_t)(live ? q : nslab - 1) * TN_BK;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t m = m0 + 2 * (2 * wave + j) + fsub;
-      const bool okm = live && m < m_end;
-      const unsigned char* sa = okm ? abase + 2 * (m * J.lda + ca[j]) : zero;
-      glds16(sa, st + j * 1024);
-      bool okb = okm;
-      if (T > 0) okb = okb && (unsigned)(tpos[j] + shift) < (unsigned)T;
-      const unsigned char* sb = okb ? bbase + 2 * ((m + shift) * J.ldb + cb[j]) : zero;
-      glds16(sb, st + TN_IMG + j * 1024);
-      if (T > 0 && live) { tpos[j] += tstep; if (tpos[j] >= T) tpos[j] -= T; }
+    {
+      const bool okm = rrow[j] < nrows;
+      const bool okb = okm && (T <= 0 || (unsigned)(tpos[j] + shift) < (unsigned)T);
+      const uint64_t sa = okm ? pa[j] : zero64, sb = okb ? pb[j] : zero64;
+      glds16(reinterpret_cast<const void*>(sa), st + j * 1024);
+      glds16(reinterpret_cast<const void*>(sb), st + TN_IMG + j * 1024);
+      pa[j] += (uint64_t)step_a; pb[j] += (uint64_t)step_b; rrow[j] += TN_BK;
+      if (T > 0) { tpos[j] += tstep; if (tpos[j] >= T) tpos[j] -= T; }
     }
   };
+  auto issue = [&](int, int stage) { issue_half(stage, 0); issue_half(stage, 1); };
   issue(0, 0); issue(1, 1); issue(2, 2);
 
   // ---- fragment reads (transposing): lane -> k-row 8*(g>>1) + qq (+4 for the second half), bytes of the 32-column
@@ -646,13 +662,26 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
     if (want_db) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wn ? a[1] : a[0], ones, bacc, 0, 0, 0);
   };
 
-  int sidx = 0;
+  // Software pipeline over the slabs, one barrier per slab: a wave multiplies slab q from fragments it fetched during
+  // the previous interval, then fetches slab q+1's, issues its share of slab q+4 and waits for its pieces of slab q+2.
+  // The LDS reads are never waited for right after they are issued (a burst that is drained at once runs the LDS at
+  // half its rate with two waves per SIMD, and that wait used to sit in front of every slab's MFMAs).
+  //   landing: every wave waits for ITS pieces of slab q+2 before the barrier that ends interval q; slab q+2 is first
+  //   read in interval q+1.  reuse: slab q+4 goes to the stage slab q-1 occupied (five stages, all of the LDS), whose
+  //   fragments every wave had in registers, and multiplied, before the barrier that starts interval q.
+  // Measured with cycle stamps (-DMM16_STAMPS, scripts/tn_stamps.py), per wave and slab: 24 fragment reads 240-390
+  // cycles of issue, 4 direct-to-LDS loads 410-740 (the CU's vector-memory path takes a 1-KiB piece every ~20 cycles and
+  // all eight waves queue for it), 16 MFMAs 680: a wave's own instruction stream is ~1700 cycles per slab against 896
+  // cycles of matrix-pipe time per SIMD, so running the two waves of a SIMD out of phase (tried three ways: one slab
+  // apart, one phase apart with two barriers per slab, opposite order of the two parts) changes nothing, and the fetch and
+  // the refill issued in two halves, one behind each half of a slab's MFMAs, is 4-6 % slower.
+  if (!(p.dbg & 4)) issue(3, 3);
+  wait_vm<2 * 4>();                        // this wave's pieces of slabs 0 and 1 have landed
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
   TnFrags f0, f1;
-  for (int q = 0; q < nslab; ++q) {
-    wait_vm<2 * 4>();                      // slab q has landed once at most the loads of slabs q+1, q+2 (4 per wave each) are outstanding
-    __builtin_amdgcn_s_barrier();          // everybody's part of slab q is in LDS; everybody is done with slab q-1
-    if (!(p.dbg & 4)) issue(q + 3, (sidx + 3) & 3);          // into the stage slab q-1 occupied
-    const uint32_t so = (uint32_t)(sidx * TN_STAGE);
+  auto fetch = [&](int stage) {
+    const uint32_t so = (uint32_t)(stage * TN_STAGE);
     uint32_t aa[2], ab[4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) aa[i] = fa[i] + so;
@@ -660,12 +689,51 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
     for (int j = 0; j < 4; ++j) ab[j] = fb[j] + so;
     tn_fetch<0>(aa, ab, f0);
     tn_fetch<16 * 512>(aa, ab, f1);
-    tn_landed<12>(f0);
+  };
+  fetch(0);
+  int sq = 0;                              // stage of slab q
+#ifdef MM16_STAMPS
+  unsigned long long ts_[12], sum_[12] = {0};
+#define TN_LAND0(f) tn_landed<0>(f)        /* scalar-memory stamps share the counter of the LDS reads: no counted waits */
+#else
+#define TN_LAND0(f) tn_landed<12>(f)
+#endif
+  for (int q = 0; q < nslab; ++q) {
+    const int s1 = sq + 1 == TN_ST ? 0 : sq + 1;             // stage of slab q+1
+    const int s4 = sq == 0 ? TN_ST - 1 : sq - 1;             // stage of slab q+4 = the one slab q-1 occupied
+    TSTAMP(0);
+    TN_LAND0(f0);
+    TSTAMP(1);
     if (!(p.dbg & 2)) mma(f0);
+    TSTAMP(2);
     tn_landed<0>(f1);
+    TSTAMP(3);
     if (!(p.dbg & 2)) mma(f1);
-    sidx = (sidx + 1) & 3;
+    __builtin_amdgcn_sched_barrier(0);
+    TSTAMP(4);
+    fetch(s1);
+    TSTAMP(5);
+    if (!(p.dbg & 4)) issue(q + 4, s4);
+    TSTAMP(6);
+    wait_vm<2 * 4>();                      // this wave's pieces of slab q+2 have landed (those of q+3, q+4 may be in flight)
+    TSTAMP(7);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef MM16_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // [0] wait f0, [1] mma f0 issue, [2] wait f1, [3] mma f1 issue, [4] fetch issue, [5] refill issue, [6] wait vm
+    for (int i = 0; i < 7; ++i) sum_[i] += ts_[i + 1] - ts_[i];
+#endif
+    sq = s1;
   }
+#ifdef MM16_STAMPS
+  if (lane == 0 && (wave == 0 || wave == 4)) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_tn_stamps[(wave ? 16 : 0) + i], sum_[i]);
+    atomicAdd(&g_tn_stamps[(wave ? 16 : 0) + 15], (unsigned long long)nslab);
+  }
+#endif
+  tn_landed<0>(f0);                        // (fragments of the slab beyond the last: fetched, never multiplied)
+  tn_landed<0>(f1);
 
   // ---- accumulate the tile: lanes run along a row of C (two 128-byte segments per instruction)
   if ((p.dbg & 1) && acc[0][0][0] != 123.456f) return;

@@ -28,12 +28,27 @@ class DataParallelPlan:
         self.lo, self.hi = slice_bounds(global_batch, self.world, self.rank)
         self.local_count = self.hi - self.lo
 
+    def _through_host(self, t):
+        """gloo with device tensors -- rehearsals of the multi-rank logic with several processes on ONE GPU; the product's
+        backend is RCCL -- was seen to hang now and then with eight processes on one card (in all_reduce and in
+        all_gather alike): there the collective runs on a host copy, ordered after the current stream's work."""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def all_reduce(self, *tensors):
         """Sum the given tensors over the ranks (no-op for a single process)."""
         if self.world == 1:
             return
         for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self._through_host(t):
+                h = t.cpu()                      # (waits for the current stream's work on t)
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    class _Done:
+        def wait(self):
+            return True
 
     def all_reduce_async(self, t):
         """Start summing ``t`` over the ranks; returns a handle whose wait() orders the current stream after the
@@ -41,6 +56,9 @@ class DataParallelPlan:
         stream that is current at the call."""
         if self.world == 1:
             return None
+        if self._through_host(t):
+            self.all_reduce(t)
+            return self._Done()
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def all_gather_cat(self, t):
@@ -55,8 +73,9 @@ class DataParallelPlan:
         mine[:t.shape[0]].copy_(t)
         allbuf = torch.empty((self.world * longest,) + tail, dtype=t.dtype, device=t.device)
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
-            # gloo has no single-buffer all-gather for device tensors (rehearsals on one GPU): per-rank views of the same buffer
-            dist.all_gather(list(allbuf.view((self.world, longest) + tail).unbind(0)), mine, group=self.group)
+            host = torch.empty(allbuf.shape, dtype=t.dtype)            # see _through_host
+            dist.all_gather_into_tensor(host, mine.cpu(), group=self.group)
+            allbuf.copy_(host)
         else:
             dist.all_gather_into_tensor(allbuf, mine, group=self.group)
         if all(hi - lo == longest for lo, hi in bounds):

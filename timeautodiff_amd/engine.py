@@ -82,6 +82,10 @@ class FlatParams:
         self.m = torch.zeros(self.n_active, dtype=torch.float32, device=device)
         self.v = torch.zeros(self.n_active, dtype=torch.float32, device=device)
         self.step = 0
+        # device-side step counter and bias-correction factors of captured optimizer steps (see adam_state); allocated
+        # here, never inside a capture (a captured allocation would be re-zeroed by every replay)
+        self._coef = torch.zeros(4, dtype=torch.float32, device=device)
+        self._dev_step = 0
         self.shapes = {n: tuple(p.shape) for n, p in params.items()}
         self.version = 0          # bumped whenever parameter values change
         # weight-gradient products are off the critical path of a backward pass (nothing downstream reads them
@@ -193,9 +197,6 @@ class FlatParams:
     def adam_state(self):
         """Device-side optimizer state of captured steps: float32[4] = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step),
         the step counter (int32 bits), unused}; ``_dev_step`` mirrors the counter on the host."""
-        if getattr(self, "_coef", None) is None:
-            self._coef = torch.zeros(4, dtype=torch.float32, device=self.device)
-            self._dev_step = 0
         return self._coef
 
     def adam_captured(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, upto=None):
