@@ -174,6 +174,9 @@ def trace_step(step_fn, ms_step, ops, fp=None, peak_flops=PEAK_BF16, NTR=3):
     else:
         roof = dict(bound="mfma", achieved=round(fl_l / avg_s / 1e12, 2), peak=peak_flops / 1e12, unit="TFLOP/s",
                     frac=round(fl_l / avg_s / peak_flops, 4), traffic=None)
+    # both fractions, whichever bound the kernel's algorithmic intensity puts it under: the weight-gradient launch sits
+    # near the ridge (245-316 FLOP per algorithmic byte against 312) and changes sides with the shape
+    roof.update(frac_of_mfma_peak=round(fl_l / avg_s / peak_flops, 4), frac_of_hbm_peak=round(by_l / avg_s / PEAK_HBM, 4))
     roof.update(kernel=dom, avg_launch_us=round(avg_s * 1e6, 2), launches_per_step=d["calls"] // NTR,
                 algorithmic_bytes_per_launch=round(by_l), algorithmic_flops_per_launch=round(fl_l),
                 issued_flops_per_launch=round(d["issued"] / d["calls"]),

@@ -327,8 +327,30 @@ __device__ __forceinline__ float bf16_rt(float v) {
 }
 
 // ---------------------------------------------------------------------------
+// (batch tile, direction) of a workgroup of a 1-D grid.  With two directions and xcd_dirs set, the workgroups that share
+// an XCD (blocks b and b + 8 do under the round-robin dispatch that is observed: a placement for speed, nothing depends
+// on it) all work on ONE direction, so that an XCD's L2 holds one direction's W_hh image instead of two: at H = 512 the
+// two images (2 x 2 MB for the LSTM) are the whole L2 and the per-step stream of W_hh came from beyond it.
+__device__ __forceinline__ bool rnn_block(int ntiles, int ndir, int xcd_dirs, int& tile, int& dir) {
+  const int bid = blockIdx.x;
+  if (ndir == 2 && xcd_dirs) { const int x = bid & 7; dir = x & 1; tile = (bid >> 3) * 4 + (x >> 1); }
+  else { dir = bid / ntiles; tile = bid - dir * ntiles; }
+  return tile < ntiles;
+}
+inline unsigned rnn_grid(int64_t ntiles, int ndir, int xcd_dirs) {
+  return (unsigned)((ndir == 2 && xcd_dirs) ? cdiv64(ntiles, 4) * 8 : ntiles * ndir);
+}
+// Measured: H = 512 (two images of 1.5-2 MB) 1-4 % faster with one direction per XCD, H = 200 (2 x 320 KB) 0-4 % slower: the
+// stream of W_hh is bound by what a CU's vector memory path takes in (44 GB/s per CU at H = 512), not by where in the
+// cache hierarchy it comes from.  On when the two images together exceed 3 MB.
+inline int rnn_xcd_dirs(int64_t H, int G) {
+  static const char* e = getenv("TAD_RNN_XCD");      // experiments: 0 = tiles of direction 0, then of direction 1; 1 = always
+  return e ? atoi(e) : (2 * G * H * H * 2 > 3 * 1024 * 1024);
+}
+
 struct RnnFwdArgs {
   tad_rnn_dir_t d[MAXDIR];
+  int ntiles, ndir, xcd_dirs;
   int B, T, H, NJ, nk, lds_ld, rpw;
   int kl;      // leading k-blocks of every chunk's W_hh image kept in LDS for the whole sequence
   int out16_rows;   // 1: the bf16 copy of h_t is written from the LDS tile in 16-byte pieces (bf16 precision, aligned rows)
@@ -350,10 +372,12 @@ __global__ __launch_bounds__(512) void rnn_fwd_kernel(RnnFwdArgs a) {
   typedef Slots<ST16> SL;
   typedef typename SL::raw raw_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const tad_rnn_dir_t d = a.d[blockIdx.y];
+  int tile_, dir_;
+  if (!rnn_block(a.ntiles, a.ndir, a.xcd_dirs, tile_, dir_)) return;
+  const tad_rnn_dir_t d = a.d[dir_];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int col = lane & 31;
-  const int64_t b0 = (int64_t)blockIdx.x * a.rpw;   // rows >= rpw of the 32-row MFMA tile stay empty
+  const int64_t b0 = (int64_t)tile_ * a.rpw;   // rows >= rpw of the 32-row MFMA tile stay empty
   const size_t buf_bytes = (size_t)a.tile_rows * a.lds_ld * ESZ;
   const int H = a.H, T = a.T;
   const int rlive = RL > 0 ? RL : (a.rpw >> 1);     // accumulator registers that hold real rows (rpw is 8, 16 or 32)
@@ -567,10 +591,12 @@ __global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
   typedef typename SL::raw raw_t;
   typedef __attribute__((ext_vector_type(4))) float f32x4v;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const tad_rnn_dir_t d = a.d[blockIdx.y];
+  int tile_, dir_;
+  if (!rnn_block(a.ntiles, a.ndir, a.xcd_dirs, tile_, dir_)) return;
+  const tad_rnn_dir_t d = a.d[dir_];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, c16 = lane & 15;
-  const int64_t b0 = (int64_t)blockIdx.x * RPW;
+  const int64_t b0 = (int64_t)tile_ * RPW;
   const size_t buf_bytes = (size_t)RPW * a.lds_ld * 2;
   const int H = a.H, T = a.T;
   // the 16-row-form image follows the 32-row-form image in the packed buffer
@@ -730,6 +756,7 @@ __global__ __launch_bounds__(512) void rnn_fwd16_kernel(RnnFwdArgs a) {
 // ---------------------------------------------------------------------------
 struct RnnBwdArgs {
   tad_rnn_bwd_dir_t d[MAXDIR];
+  int ntiles, ndir, xcd_dirs;
   int B, T, H, NJ, width, lds_ld, nk_total, nk_gate, rpw;
   int kl;      // leading k-blocks of every chunk's transposed W_hh image kept in LDS for the whole sequence (one-pass bf16 form)
 };
@@ -745,10 +772,12 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
   typedef Slots<ST16> SL;
   typedef typename SL::raw raw_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const tad_rnn_bwd_dir_t d = a.d[blockIdx.y];
+  int tile_, dir_;
+  if (!rnn_block(a.ntiles, a.ndir, a.xcd_dirs, tile_, dir_)) return;
+  const tad_rnn_bwd_dir_t d = a.d[dir_];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int col = lane & 31;
-  const int64_t b0 = (int64_t)blockIdx.x * a.rpw;   // rows >= rpw of the 32-row MFMA tile stay empty
+  const int64_t b0 = (int64_t)tile_ * a.rpw;   // rows >= rpw of the 32-row MFMA tile stay empty
   const int H = a.H, T = a.T;
   const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed_t);
   const int half = lane >> 5;
@@ -1185,7 +1214,8 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
   size_t lds = (size_t)2 * 32 * a.lds_ld * (bf ? 2 : 4);
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_fwd: H=%ld needs %zu bytes of LDS in this precision (limit %zu)", (long)H, lds, LDS_LIMIT);
   a.kl = 0;
-  dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
+  a.ndir = ndir; a.xcd_dirs = rnn_xcd_dirs(H, G); a.ntiles = (int)cdiv64(B, a.rpw);
+  dim3 grid(rnn_grid(a.ntiles, ndir, a.xcd_dirs)), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
   {
     // The 16-row form, if W_hh fits its registers + LDS, at 8 rows per workgroup: the sampler, and training at the
@@ -1208,7 +1238,8 @@ extern "C" int tad_rnn_fwd(int cell, int prec, int store, int64_t B, int64_t T, 
       b.out16_rows = H % 8 == 0;
       for (int i = 0; i < ndir; ++i)
         if (dirs[i].out16 && (dirs[i].ld_out16 % 8 != 0 || (reinterpret_cast<uintptr_t>(dirs[i].out16) & 15) != 0)) b.out16_rows = 0;
-      dim3 grid16((unsigned)cdiv64(B, rpw), (unsigned)ndir);
+      b.ntiles = (int)cdiv64(B, rpw);
+      dim3 grid16(rnn_grid(b.ntiles, ndir, b.xcd_dirs));
       if (cell == TAD_CELL_LSTM)
         return stash ? launch_fwd16<TAD_CELL_LSTM, F16_NKR_LSTM, 8, true>(b, grid16, block, need, s)
                      : launch_fwd16<TAD_CELL_LSTM, F16_NKR_LSTM, 8, false>(b, grid16, block, need, s);
@@ -1288,7 +1319,8 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, 
   a.lds_ld = (phased ? g.width : G * g.width) + pad;
   lds = (size_t)32 * a.lds_ld * esz;
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_bwd: H=%ld needs %zu bytes of LDS (limit %zu)", (long)H, lds, LDS_LIMIT);
-  dim3 grid((unsigned)cdiv64(B, a.rpw), (unsigned)ndir), block((unsigned)g.nw * 64);
+  a.ndir = ndir; a.xcd_dirs = rnn_xcd_dirs(H, G); a.ntiles = (int)cdiv64(B, a.rpw);
+  dim3 grid(rnn_grid(a.ntiles, ndir, a.xcd_dirs)), block((unsigned)g.nw * 64);
   hipStream_t s = (hipStream_t)stream;
   a.kl = 0;
   if (bf && g.jpw == 1 && !phased) {
