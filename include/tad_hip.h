@@ -235,9 +235,24 @@ typedef struct {
 int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir,
                 const tad_rnn_bwd_dir_t* dirs, tad_stream_t stream);
 
+/* tad_rnn_fwd with device memory for the forms that split the hidden units of a batch tile over several workgroups
+ * (bf16 precision and storage at H = 512, where one direction's W_hh fits no CU: eight workgroups of 64 units each keep
+ * it in registers and hand their columns of h_t to each other through the workspace every step; DIFF.py:182 -> 220 and
+ * VAE.py:119-120 -> 154-155 at hidden_size 512).  tad_rnn_workspace_bytes: what such a form needs for this call, 0 when
+ * the shape has none.  workspace: that many bytes, 16-byte aligned, zeroed once by the caller after allocating it,
+ * used by one launch at a time (launches that overlap on the device need workspaces of their own); NULL or too small,
+ * or pointers / leading dimensions the form cannot take (xproj and gate stash: 16-byte aligned, ld % 8 == 0): the call
+ * is tad_rnn_fwd.  Same results as tad_rnn_fwd up to the order of the fp32 sums.  The workgroups of such a launch wait
+ * for each other; a wait that runs out of time (0.5 s: the device could not hold the launch's workgroups at once) ends
+ * the launch and sets a word in the workspace that tad_rnn_ws_status (synchronises the stream) reports as an error. */
+int64_t tad_rnn_workspace_bytes(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir);
+int tad_rnn_fwd_ws(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
+                   void* workspace, int64_t workspace_bytes, tad_stream_t stream);
+int tad_rnn_ws_status(const void* workspace, tad_stream_t stream);
+
 /* Bytes of ONE packed buffer (forward or backward) of a recurrent weight matrix W_hh[G*H,H].  In bf16 precision
- * the forward buffer holds two images: the one the 32-row MFMA forms read and, behind it, the one of the 16-row form
- * that launches of 8 batch rows per workgroup take (every reverse step of `sample`, DIFF.py:340-351, at up to 2047
+ * the forward buffer holds up to three images: the one the 32-row MFMA forms read, behind it the one of the 16-row form
+ * that launches of 8 batch rows per workgroup take, and at H = 512 the one of tad_rnn_fwd_ws's cluster form (every reverse step of `sample`, DIFF.py:340-351, at up to 2047
  * sequences per call; training at the reference's batch of 100, DIFF.py:305-328). */
 int64_t tad_rnn_packed_bytes(int prec, int64_t H, int G);
 /* Re-lay W_hh[G*H,H] (row stride H) into the MFMA-fragment-ordered images the

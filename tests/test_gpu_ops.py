@@ -223,7 +223,7 @@ IN_SLOTS = {0: (0, 1, 2, 3), 1: (0, 1, 2, -1)}
 HID_SLOTS = {0: (0, 1, 2, 3), 1: (0, 1, -1, 2)}
 
 
-def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11):
+def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11, cluster=False):
     """One layer, len(rev_flags) directions sharing the input, through the C ABI exactly as the engine drives
     it: pack -> input GEMM -> sequence kernel -> BPTT kernel -> weight / bias / input gradients.  bf16 storage
     of the per-timestep tensors is used when the shapes allow it (H even, IN a multiple of 8).
@@ -274,7 +274,23 @@ def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11):
                           gates=gates[:, sl], cstate=cst[:, hl] if cell == 0 else None, reverse=rev))
         bdirs.append(dict(dout=doutd[:, hl], gates=gates[:, sl], cstate=cst[:, hl] if cell == 0 else None,
                           out=out[:, hl] if cell == 1 else None, w_packed_t=pb[d], dgates=dg[:, sl], reverse=rev))
-    ops.rnn_fwd(cell, prec, B, T, H, fdirs)
+    fwd_kernel = None
+    if cluster:
+        # the form that splits a batch tile's hidden units over eight workgroups: needs device memory for the exchange
+        nws = ops.rnn_workspace_bytes(cell, prec, 1 if s16 else 0, B, T, H, nd)
+        assert nws > 0
+        wsp = torch.zeros(nws, dtype=torch.uint8, device=dev)
+        ops.rnn_fwd(cell, prec, B, T, H, fdirs, workspace=wsp)
+        fwd_kernel = ops._lib.load().tad_last_kernel().decode()
+        ops.rnn_ws_status(wsp)
+        # and once more without the stash (inference): the same h
+        out_inf = torch.zeros_like(out)
+        idirs = [dict(d, gates=None, cstate=None, out=out_inf[:, k * H:(k + 1) * H]) for k, d in enumerate(fdirs)]
+        ops.rnn_fwd(cell, prec, B, T, H, idirs, workspace=wsp)
+        ops.rnn_ws_status(wsp)
+        assert torch.equal(out_inf, out)
+    else:
+        ops.rnn_fwd(cell, prec, B, T, H, fdirs)
     ops.rnn_bwd(cell, prec, B, T, H, bdirs)
     dWih = torch.zeros(nd * GH, IN, device=dev)
     dbih, dbhh = torch.zeros(nd * GH, device=dev), torch.zeros(nd * GH, device=dev)
@@ -293,7 +309,8 @@ def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11):
     unglue = lambda t: t.float().view(BT, nd, H, 4).permute(0, 1, 3, 2).cpu().numpy()      # -> [BT, nd, slot, H]
     return dict(out=out.cpu().numpy(), gates=unglue(gates), cst=cst.cpu().numpy(), xproj=unglue(xproj), dg=unglue(dg),
                 dWih=dWih.view(nd, GH, IN).cpu().numpy(), dWhh=dWhh.cpu().numpy(), dbih=dbih.view(nd, GH).cpu().numpy(),
-                dbhh=dbhh.view(nd, GH).cpu().numpy(), dx=dx.cpu().numpy(), oracle=oracle, x=x, dout=dout, G=G, s16=s16)
+                dbhh=dbhh.view(nd, GH).cpu().numpy(), dx=dx.cpu().numpy(), oracle=oracle, x=x, dout=dout, G=G, s16=s16,
+                fwd_kernel=fwd_kernel)
 
 
 def _check_rnn(r, cell, B, T, H, tol):
@@ -360,6 +377,22 @@ def test_rnn_heads_layout_at_hidden_512(ops, dev, cell):
     rng = np.random.default_rng(512 + cell)
     r = _run_rnn(ops, dev, cell, 1, B, T, H, [False, False], rng, IN=IN)
     assert r["s16"]
+    _check_rnn(r, cell, B, T, H, BF16_EMU_TOL)
+
+
+@pytest.mark.parametrize("B,T,revs", [(4100, 3, (False, True)), (4100, 2, (False, False)), (100, 6, (False, True)), (60, 4, (False,)),
+                                      (70, 5, (True,))])
+@pytest.mark.parametrize("cell", [0, 1])
+def test_rnn_cluster_form_at_hidden_512(ops, dev, cell, B, T, revs):
+    """tad_rnn_fwd_ws at H = 512, bf16: eight workgroups per 128 batch rows, each with 64 hidden units' rows of W_hh in
+    registers, exchanging h_t through the workspace every step.  Outputs and stash (and the gradients the backward makes of
+    them) against the oracle as for the other forms; 4100 rows = 33 tiles x 2 directions is more work items than groups
+    fit the chip at once (a group walks several items and re-uses its exchange buffers), with a ragged last tile; 100, 70 and
+    60 rows fill the second half of a tile partly / not at all.  The launch without a stash returns the same h bit for bit."""
+    H, IN = 512, 16
+    rng = np.random.default_rng(5120 + cell + B + T)
+    r = _run_rnn(ops, dev, cell, 1, B, T, H, list(revs), rng, IN=IN, cluster=True)
+    assert r["s16"] and r["fwd_kernel"].startswith("rnn_cluster_fwd_kernel"), r["fwd_kernel"]
     _check_rnn(r, cell, B, T, H, BF16_EMU_TOL)
 
 

@@ -64,6 +64,9 @@ PROTOTYPES = {
     "tad_colsum": (_i, [_i64, _i64, _p, _i64, _p, _i64, _f, _p, _p, _p, _p]),
     "tad_enc_grad_b16": (_i, [_i64, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p]),
     "tad_rnn_fwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p]),
+    "tad_rnn_workspace_bytes": (_i64, [_i, _i, _i, _i64, _i64, _i64, _i]),
+    "tad_rnn_fwd_ws": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p, _i64, _p]),
+    "tad_rnn_ws_status": (_i, [_p, _p]),
     "tad_rnn_bwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnBwdDir), _p]),
     "tad_rnn_pack_input": (_i, [_i, _i64, _i64, _i, _p, _p, _p, _p, _i, _i64, _p, _p]),
     "tad_rnn_packed_bytes": (_i64, [_i, _i64, _i]),

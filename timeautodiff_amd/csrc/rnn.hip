@@ -13,6 +13,7 @@
 // Accumulator layout (v_mfma_f32_32x32x*): column = lane & 31 = unit within the chunk,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = batch row within the tile.
 #include "common.h"
+#include "rnn_layout.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -115,6 +116,31 @@ __device__ __forceinline__ void pack16_elem(const Pack16Args& a, int64_t gid) {
 }
 __global__ void pack16_kernel(Pack16Args a) { pack16_elem(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
 
+// Forward image for the cluster form (H a multiple of 64): blocks [mw][kk] of 64 uint4, mw = 0 .. H/8 - 1 the wave
+// (8 per workgroup) that owns units 8 mw .. 8 mw + 7.  W is the A operand of v_mfma_f32_32x32x16_bf16 there: lane l
+// holds row m = l % 32 of the wave's 32 gate rows, columns k = 16 kk + 8 (l / 32) + e, e = 0..7; row m is slot m % 4 of
+// unit 8 mw + 4 ((m / 4) % 2) + m / 8, so that a lane of the result (row = (reg % 4) + 8 (reg / 4) + 4 (lane / 32)) holds
+// the four slots of four neighbouring units.  Slot 3 of a GRU is zeros.
+__device__ __forceinline__ void pack_cluster_elem(const float* w, uint4* out, int H, int G, int64_t gid) {
+  const int lane = gid & 63;
+  const int64_t blk = gid >> 6;
+  const int ks = H / 16;
+  if (blk >= (int64_t)(H / 8) * ks) return;
+  const int kk = (int)(blk % ks), mw = (int)(blk / ks);
+  const int m = lane & 31, slot = m & 3, unit = 8 * mw + 4 * ((m >> 2) & 1) + (m >> 3);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * kk + 8 * (lane >> 5) + e;
+    v[e] = slot < G ? w[((int64_t)slot * H + unit) * H + k] : 0.f;
+  }
+  uint4 o;
+  o.x = pk2(v[0], v[1]); o.y = pk2(v[2], v[3]); o.z = pk2(v[4], v[5]); o.w = pk2(v[6], v[7]);
+  out[gid] = o;
+}
+struct PackClArgs { const float* w; uint4* out; int H, G; };
+__global__ void pack_cluster_kernel(PackClArgs a) { pack_cluster_elem(a.w, a.out, a.H, a.G, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+
 // Every image of up to 16 recurrent weight matrices of one shape in ONE launch (blockIdx.y = matrix; the threads of a
 // matrix cover its forward image, then its backward image, then its 16-row-form image): a model's images are rebuilt
 // after every optimizer step, and two dozen launches of a few microseconds each were 2 % of a training step.
@@ -124,17 +150,19 @@ struct PackMultiArgs {
   uint4* fwd[PACK_MAXJOBS];
   uint4* bwd[PACK_MAXJOBS];
   int H, G, NJ, nkf, nkb, nk32, width, bf16;
-  int64_t nf, nb, n16;      // threads of the three images
+  int64_t nf, nb, n16, ncl;      // threads of the images: 32-row forward, backward, 16-row forward, cluster forward
 };
 __global__ void pack_multi_kernel(PackMultiArgs a) {
   const int job = blockIdx.y;
-  for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < a.nf + a.nb + a.n16; gid += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < a.nf + a.nb + a.n16 + a.ncl; gid += (int64_t)gridDim.x * blockDim.x) {
     if (gid < a.nf) {
       if (a.fwd[job]) pack_elem(PackArgs{a.w[job], a.fwd[job], a.H, a.G, a.NJ, a.nkf, a.width, a.bf16, 0}, gid);
     } else if (gid < a.nf + a.nb) {
       if (a.bwd[job]) pack_elem(PackArgs{a.w[job], a.bwd[job], a.H, a.G, a.NJ, a.nkb, a.width, a.bf16, 1}, gid - a.nf);
+    } else if (gid < a.nf + a.nb + a.n16) {
+      if (a.fwd[job]) pack16_elem(Pack16Args{a.w[job], a.fwd[job] + a.nf, a.H, a.G, a.NJ, a.nk32}, gid - a.nf - a.nb);
     } else if (a.fwd[job]) {
-      pack16_elem(Pack16Args{a.w[job], a.fwd[job] + a.nf, a.H, a.G, a.NJ, a.nk32}, gid - a.nf - a.nb);
+      pack_cluster_elem(a.w[job], a.fwd[job] + a.nf + a.n16, a.H, a.G, gid - a.nf - a.nb - a.n16);
     }
   }
 }
@@ -1112,8 +1140,8 @@ int launch_bwd(const RnnBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream
 extern "C" int64_t tad_rnn_packed_bytes(int prec, int64_t H, int G) {
   if (H <= 0 || (G != 3 && G != 4) || (prec != TAD_F32 && prec != TAD_BF16)) return -1;
   const Geom g = geom(prec, H, G);
-  // (forward buffer: the 32-row-form image, then in bf16 precision the 16-row-form image)
-  const int64_t f = (int64_t)g.NJ * g.nkf * G + (int64_t)g.NJ * g.nk32 * G * 2, b = (int64_t)g.NJ * g.nkb;
+  // (forward buffer: the 32-row-form image, then in bf16 precision the 16-row-form image, then the cluster-form image)
+  const int64_t f = rnn_fwd_image_blocks(prec, H, G) + rnn_cluster_image_blocks(prec, H), b = (int64_t)g.NJ * g.nkb;
   return (f > b ? f : b) * 1024;
 }
 
@@ -1142,6 +1170,12 @@ extern "C" int tad_rnn_pack_weights(int prec, int64_t H, int G, const float* w_h
     hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, (hipStream_t)stream, a);
     TAD_LAUNCH_CHECK();
   }
+  if (packed_fwd && rnn_cluster_image_blocks(prec, H) > 0) {
+    PackClArgs a{w_hh, reinterpret_cast<uint4*>(packed_fwd) + rnn_fwd_image_blocks(prec, H, G) * 64, (int)H, G};
+    const int64_t threads = rnn_cluster_image_blocks(prec, H) * 64;
+    hipLaunchKernelGGL(pack_cluster_kernel, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    TAD_LAUNCH_CHECK();
+  }
   return TAD_OK;
 }
 
@@ -1159,7 +1193,8 @@ extern "C" int tad_rnn_pack_weights_multi(int prec, int64_t H, int G, int njobs,
   }
   a.H = (int)H; a.G = G; a.NJ = g.NJ; a.nkf = g.nkf; a.nkb = g.nkb; a.nk32 = g.nk32; a.width = g.width; a.bf16 = prec == TAD_BF16;
   a.nf = (int64_t)g.NJ * g.nkf * G * 64; a.nb = (int64_t)g.NJ * g.nkb * 64; a.n16 = (int64_t)g.NJ * g.nk32 * G * 2 * 64;
-  int64_t gx = cdiv64(a.nf + a.nb + a.n16, 256);
+  a.ncl = rnn_cluster_image_blocks(prec, H) * 64;
+  int64_t gx = cdiv64(a.nf + a.nb + a.n16 + a.ncl, 256);
   if (gx > 256) gx = 256;
   hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)gx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, a);
   TAD_LAUNCH_CHECK();

@@ -513,7 +513,11 @@ class RnnStack:
                                  out16=out16[:, hs] if out16 is not None else None, gates=gates[:, sl] if train else None,
                                  cstate=cst[:, hs] if cst is not None else None, reverse=self.rev[d]))
             fp.release()
-            ops.rnn_fwd(self.cell, prec, B, T, H, dirs)
+            # H = 512 in bf16: the form that keeps W_hh on chip, split over eight workgroups that exchange h_t through
+            # device memory (one buffer per stack and workspace: the launches of a stream follow each other)
+            wsb = ops.rnn_workspace_bytes(self.cell, prec, BF16 if sdt == torch.bfloat16 else F32, B, T, H, nd)
+            cl_ws = ws.get(f"{tag}.rnn_ws", (wsb,), dtype=torch.uint8, zero="new") if wsb > 0 else None
+            ops.rnn_fwd(self.cell, prec, B, T, H, dirs, workspace=cl_ws)
             inp = out16 if (not last and self.mm16[layer + 1] and out16 is not None) else out
         return inp
 

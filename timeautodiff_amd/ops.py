@@ -459,9 +459,20 @@ def rnn_pack_input(cell, H, w_ih, b_ih, b_hh, w_gl, bias_gl):
           bias_gl.data_ptr(), _stream())
 
 
-def rnn_fwd(cell, prec, B, T, H, dirs):
+def rnn_workspace_bytes(cell, prec, store, B, T, H, ndir):
+    """Device memory the forms of rnn_fwd that split a batch tile's hidden units over several workgroups need (0: none)."""
+    return _lib.load().tad_rnn_workspace_bytes(cell, prec, store, B, T, H, ndir)
+
+
+def rnn_ws_status(workspace):
+    """Raises if a launch that used ``workspace`` gave up waiting (synchronises the stream)."""
+    _lib.check(_lib.load().tad_rnn_ws_status(workspace.data_ptr(), _stream()))
+
+
+def rnn_fwd(cell, prec, B, T, H, dirs, workspace=None):
     """dirs: list of dict(xproj (2-d view, float32 or bfloat16, gate-interleaved), w_packed, b_hh, out,
-    gates (same dtype as xproj, or None = inference), cstate (LSTM training), reverse)."""
+    gates (same dtype as xproj, or None = inference), cstate (LSTM training), reverse).  workspace: a zero-initialised
+    uint8 tensor of rnn_workspace_bytes(...) bytes that no other launch in flight uses, or None."""
     arr = (RnnDir * len(dirs))()
     store = _store_of(dirs[0]["xproj"])
     for k, d in enumerate(dirs):
@@ -485,8 +496,12 @@ def rnn_fwd(cell, prec, B, T, H, dirs):
     train = dirs[0].get("gates") is not None
     h_bytes = (4 if dirs[0].get("out") is not None else 0) + (2 if dirs[0].get("out16") is not None else 0)
     per_elem = 4 * esz + h_bytes + ((4 * esz + (4 if cell == CELL_LSTM else 0)) if train else 0)     # xproj in, h out, stash out
-    _call("tad_rnn_fwd", cell, prec, store, B, T, H, nd, arr, _stream(),
-          cost=(2.0 * B * T * nd * G * H * H, float(B * T * nd * H * per_elem)))
+    cost = (2.0 * B * T * nd * G * H * H, float(B * T * nd * H * per_elem))
+    if workspace is not None:
+        assert workspace.dtype == torch.uint8 and workspace.is_contiguous()
+        _call("tad_rnn_fwd_ws", cell, prec, store, B, T, H, nd, arr, workspace.data_ptr(), workspace.numel(), _stream(), cost=cost)
+    else:
+        _call("tad_rnn_fwd", cell, prec, store, B, T, H, nd, arr, _stream(), cost=cost)
 
 
 def rnn_bwd(cell, prec, B, T, H, dirs):
