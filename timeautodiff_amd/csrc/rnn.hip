@@ -836,7 +836,11 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
   }
 
   f32x16 acc[JPW];
-  float dcs[JPW][16];
+  float dcs[JPW][16];      // LSTM: dc carried to the step before; GRU with SPLIT_Z: dh z, the direct part of dh_{t-1}
+  // GRU: dh_{t-1} = dh z + (gate gradients) W_hh.  With one chunk per wave the accumulator of the product is seeded with
+  // dh z; with two, writing computed values into the two 16-register accumulators element by element sent the register
+  // allocator into 16 000 spilled registers, so there the accumulators start at zero and dh z is added when dh is formed.
+  constexpr bool SPLIT_Z = CELL == TAD_CELL_GRU && JPW > 1 && !PHASED;
 #pragma unroll
   for (int jj = 0; jj < JPW; ++jj)
 #pragma unroll
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
           float da[G];
           float nacc;
           // rows / units outside the batch carry zeros through the same arithmetic
-          const float dh = q_dout[jj][r] + acc[jj][r];
+          const float dh = SPLIT_Z ? (q_dout[jj][r] + acc[jj][r]) + dcs[jj][r] : q_dout[jj][r] + acc[jj][r];
           const f32x4 gv = SL::unpack(q_g[jj][r]);
           raw_t dgv;
           if constexpr (CELL == TAD_CELL_LSTM) {
@@ -951,7 +955,8 @@ __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
 #pragma unroll
             for (int g = 0; g < G; ++g) da[g] = 0.f;
           }
-          acc[jj][r] = nacc;
+          if constexpr (SPLIT_Z) { dcs[jj][r] = nacc; acc[jj][r] = 0.f; }
+          else acc[jj][r] = nacc;
           if constexpr (!PHASED) {
 #pragma unroll
             for (int g = 0; g < G; ++g) lds_put<BF16>(smem, a.lds_ld, row, g * a.width + u, da[g]);
@@ -1348,9 +1353,8 @@ extern "C" int tad_rnn_bwd(int cell, int prec, int store, int64_t B, int64_t T, 
   const int pad = bf ? 8 : 4;
   const size_t esz = bf ? 2 : 4;
   size_t lds = (size_t)32 * (G * g.width + pad) * esz;
-  // the gate-by-gate form also where the one-pass form does not fit the register file: the GRU with two chunks per
-  // wave (H = 512 in bf16) compiles to 16 000 spilled registers per lane and runs 100 times slower than it should
-  const bool phased = lds > LDS_LIMIT || (cell == TAD_CELL_GRU && g.jpw == 2);
+  static const char* phased_env = getenv("TAD_RNN_BWD_PHASED");      // experiments: 1 = the gate-by-gate form wherever it exists
+  const bool phased = lds > LDS_LIMIT || (phased_env && atoi(phased_env) == 1 && g.jpw >= 2);
   a.lds_ld = (phased ? g.width : G * g.width) + pad;
   lds = (size_t)32 * a.lds_ld * esz;
   TAD_CHECK(lds <= LDS_LIMIT, "tad_rnn_bwd: H=%ld needs %zu bytes of LDS (limit %zu)", (long)H, lds, LDS_LIMIT);
