@@ -602,7 +602,10 @@ def test_sampler_device_noise_is_counter_based(dev):
     xT2 = torch.empty(B - lo, T, K, device=dev)
     ops.sampler_noise(seed, S, lo * T, (B - lo) * T, K, xT2)
     assert torch.equal(xT2, x_T[lo:])
-    # another seed, another sample
+    # fresh noise under the same seed: another call number; another seed, another sample
+    x1 = DIFF.sample(tgrid, B, T, K, S, m, ti, cond, None, noise_source="device", noise_call=1)
+    assert torch.isfinite(x1).all() and not torch.equal(x1, ref)
+    assert torch.equal(DIFF.sample(tgrid, B, T, K, S, m, ti, cond, None, noise_source="device", noise_call=1, streams=1), x1)
     torch.manual_seed(12)
     assert not torch.equal(DIFF.sample(tgrid, B, T, K, S, m, ti, cond, None, noise_source="device"), ref)
 

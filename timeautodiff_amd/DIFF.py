@@ -456,14 +456,18 @@ def train_diffusion(latent_features, cond_df, data_dict, hidden_dim, num_layers,
 @torch.no_grad()
 @ops.device_scope(lambda t, B, T, F, diffusion_steps, model, *a, **k: ops._first_cuda(model, t))
 def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, noise=None, dtype=None,
-           process_group=None, noise_source="reference", keep=None, streams=None, graph=None, local_only=False):
+           process_group=None, noise_source="reference", keep=None, streams=None, graph=None, local_only=False,
+           noise_call=0):
     """reference DIFF.py:333-352: x_T ~ N(0,I), then 100 reverse steps with the step-0 double
     update.  Loop-invariant work (cond path, t_enc, time_encode and their share of `proj`) is
     computed once; the per-step i_enc contribution is a precomputed [steps, H] table.
 
     Keyword-only extras: noise = dict(x_T=[B,T,F], z=[steps,B,T,F]) to inject the draws;
     noise_source 'reference' (torch CPU generator in the reference's order, staged to the
-    device once) or 'device'; dtype overrides the model's compute dtype; process_group shards
+    device once) or 'device' (counter-based draws: a function of (torch.initial_seed(), noise_call, step, global row),
+    NOT of how many calls were made before -- two calls under one seed return the same samples, whatever the sharding,
+    chunking or graph replay; pass noise_call = 1, 2, ... (or reseed) for fresh noise; the reference's generator
+    advances from call to call, DIFF.py:335-347, which noise_source='reference' reproduces); dtype overrides the model's compute dtype; process_group shards
     the batch over ranks with no communication inside the loop; every rank returns the whole batch [B,T,F] (one
     all-gather of the finished slices) unless local_only=True (then its own slice); keep = dict that
     receives x after the listed steps (keys = step numbers); streams = number of contiguous chunks of
@@ -493,7 +497,7 @@ def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, 
         # counter-based noise on the device, seeded like torch's generators: x_T now (counter = S), each step's z when
         # the step runs, and only the rows this rank (and each of its concurrent chunks) owns -- never the
         # [S, B, T, F] block.  A function of (seed, step, global row): the result does not depend on the sharding.
-        seed = torch.initial_seed()
+        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * int(noise_call)) & 0xFFFFFFFFFFFFFFFF
         x = torch.empty(nb, T, F, device=d)
         ops.sampler_noise(seed, S, lo * T, nb * T, F, x)
         z_all = CounterNoise(seed, S, lo * T)
