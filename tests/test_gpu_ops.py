@@ -396,6 +396,117 @@ def test_rnn_cluster_form_at_hidden_512(ops, dev, cell, B, T, revs):
     _check_rnn(r, cell, B, T, H, BF16_EMU_TOL)
 
 
+def _cluster_problem(ops, dev, cell, B, T, nd, seed):
+    """Random operands of one forward launch at H = 512 in bf16 storage, and a function that runs it into fresh outputs."""
+    H, G = 512, (4 if cell == 0 else 3)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    BT, H4 = B * T, 4 * H
+    xproj = (torch.randn(BT, nd * H4, generator=g) * 0.7).to(dev).to(torch.bfloat16)
+    whh = ((torch.rand(nd, G * H, H, generator=g) * 2 - 1) / H ** 0.5).to(dev)
+    bhh = ((torch.rand(nd, G * H, generator=g) * 2 - 1) / H ** 0.5).to(dev)
+    nbytes = ops.rnn_packed_bytes(1, H, G)
+    pf = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(nd)]
+    for d in range(nd):
+        ops.rnn_pack_weights(1, H, G, whh[d], pf[d], None)
+
+    def run(workspace, stash=True):
+        out = torch.zeros(BT, nd * H, device=dev)
+        out16 = torch.zeros(BT, nd * H, dtype=torch.bfloat16, device=dev)
+        gates = torch.zeros(BT, nd * H4, dtype=torch.bfloat16, device=dev)
+        cst = torch.zeros(BT, nd * H, device=dev)
+        dirs = [dict(xproj=xproj[:, d * H4:(d + 1) * H4], w_packed=pf[d], b_hh=bhh[d] if cell == 1 else None,
+                     out=out[:, d * H:(d + 1) * H], out16=out16[:, d * H:(d + 1) * H],
+                     gates=gates[:, d * H4:(d + 1) * H4] if stash else None,
+                     cstate=cst[:, d * H:(d + 1) * H] if (stash and cell == 0) else None, reverse=bool(d & 1)) for d in range(nd)]
+        ops.rnn_fwd(cell, 1, B, T, H, dirs, workspace=workspace)
+        return out, out16, gates, cst
+    return run
+
+
+@pytest.mark.parametrize("cell", [0, 1])
+def test_rnn_cluster_form_beside_other_work_and_replayed(ops, dev, cell):
+    """The eight workgroups of a group hand h_t to each other through device memory every step.  The launch must give the
+    same bits (a) alone on the chip, (b) while another stream keeps the chip busy with memory-bound kernels, so that the
+    workgroups of a group start at different times and meet loaded memory paths, (c) many times in a row on one workspace
+    (arrival counters are re-zeroed by every launch; the consumers' caches have seen the exchange buffers before), and
+    (d) replayed from a captured HIP graph (the memset of the counters is a node of the graph).  Against the forms that
+    need no workspace: to the tolerance of the bf16 mode (another summation order)."""
+    B, T, nd = 700, 7, 2
+    run = _cluster_problem(ops, dev, cell, B, T, nd, 77 + cell)
+    nws = ops.rnn_workspace_bytes(cell, 1, 1, B, T, 512, nd)
+    assert nws > 0
+    ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
+    ref = run(ws)
+    assert ops._lib.load().tad_last_kernel().decode().startswith("rnn_cluster_fwd_kernel")
+    ops.rnn_ws_status(ws)
+    plain = run(None)
+    assert not ops._lib.load().tad_last_kernel().decode().startswith("rnn_cluster_fwd_kernel")
+    for a, b in zip(ref, plain):
+        assert fu.rel_err(a.float().cpu().numpy(), b.float().cpu().numpy()) < BF16_EMU_TOL
+    # (b) + (c): a side stream streams 256 MB copies all the while
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, device=dev)
+    big2 = torch.empty_like(big)
+    main = torch.cuda.current_stream()
+    for rep in range(6):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                ops.copy_2d(big.view(-1, 4096), big2.view(-1, 4096))
+        got = run(ws)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), rep
+    main.wait_stream(side)
+    ops.rnn_ws_status(ws)
+    # (d) captured and replayed
+    g = torch.cuda.HIPGraph() if hasattr(torch.cuda, "HIPGraph") else torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(main)
+    with torch.cuda.stream(cap):
+        warm = run(ws)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=cap):
+            held = run(ws)
+    for rep in range(3):
+        for t in held:
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(held, ref):
+            assert torch.equal(a, b), rep
+    ops.rnn_ws_status(ws)
+
+
+@pytest.mark.parametrize("B,T,nd", [(1, 1, 1), (3, 1, 2), (33, 2, 1), (129, 3, 2)])
+def test_rnn_cluster_form_small_shapes(ops, dev, B, T, nd):
+    """One row, one step (nothing is ever handed over), a tile whose last three quarters are empty, a second tile of one row:
+    the form with the workspace against the forms without, with and without the stash."""
+    for cell in (0, 1):
+        run = _cluster_problem(ops, dev, cell, B, T, nd, 5 + B)
+        ws = torch.zeros(ops.rnn_workspace_bytes(cell, 1, 1, B, T, 512, nd), dtype=torch.uint8, device=dev)
+        got = run(ws)
+        assert ops._lib.load().tad_last_kernel().decode().startswith("rnn_cluster_fwd_kernel")
+        ops.rnn_ws_status(ws)
+        ref = run(None)
+        for a, b in zip(got, ref):
+            assert fu.rel_err(a.float().cpu().numpy(), b.float().cpu().numpy()) < BF16_EMU_TOL
+        inf = run(ws, stash=False)
+        assert torch.equal(inf[0], got[0]) and torch.equal(inf[1], got[1])
+
+
+def test_rnn_fwd_ws_falls_back_where_the_cluster_form_does_not_apply(ops, dev):
+    """Other hidden sizes, fp32, a workspace that is too small or views the form cannot address: tad_rnn_fwd_ws is
+    tad_rnn_fwd, bit for bit."""
+    assert ops.rnn_workspace_bytes(0, 1, 1, 64, 4, 200, 2) == 0 and ops.rnn_workspace_bytes(0, 0, 0, 64, 4, 512, 2) == 0
+    run = _cluster_problem(ops, dev, 0, 40, 3, 2, 9)
+    small = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    a = run(small)
+    assert not ops._lib.load().tad_last_kernel().decode().startswith("rnn_cluster_fwd_kernel")
+    b = run(None)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_rnn_bwd_phased_path(ops, dev):
     """fp32 LSTM with H = 320: the gate-gradient tile exceeds LDS and the backward kernel
     stages it gate by gate."""
