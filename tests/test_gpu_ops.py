@@ -494,6 +494,20 @@ def test_rnn_cluster_form_small_shapes(ops, dev, B, T, nd):
         assert torch.equal(inf[0], got[0]) and torch.equal(inf[1], got[1])
 
 
+def test_rnn_workspace_status_is_reported(ops, dev):
+    """The word a launch sets when its workgroups give up waiting for each other: ops.check_rnn_workspaces (called by the
+    trainers and the sampler where they synchronise) raises on it, and keeps quiet on workspaces of clean launches."""
+    run = _cluster_problem(ops, dev, 0, 64, 2, 1, 21)
+    ws = torch.zeros(ops.rnn_workspace_bytes(0, 1, 1, 64, 2, 512, 1), dtype=torch.uint8, device=dev)
+    run(ws)
+    ops.check_rnn_workspaces()
+    ws[16384:16388] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device=dev)       # what a launch that timed out leaves
+    with pytest.raises(ops._lib.TadError, match="ran out of time"):
+        ops.check_rnn_workspaces()
+    ws.zero_()
+    ops.check_rnn_workspaces()
+
+
 def test_rnn_fwd_ws_falls_back_where_the_cluster_form_does_not_apply(ops, dev):
     """Other hidden sizes, fp32, a workspace that is too small or views the form cannot address: tad_rnn_fwd_ws is
     tad_rnn_fwd, bit for bit."""

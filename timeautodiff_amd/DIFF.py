@@ -449,6 +449,7 @@ def train_diffusion(latent_features, cond_df, data_dict, hidden_dim, num_layers,
         bar.stop()
     if losses is not None:
         losses.extend(hist[:n_epochs].tolist())
+    ops.check_rnn_workspaces(trainer.eng.device)       # (synchronises; raises if a sequence launch gave up waiting)
     return model
 
 
@@ -509,6 +510,8 @@ def sample(t, B, T, F, diffusion_steps, model, time_info, cond, target_mask, *, 
     if nb > 0:          # (a rank whose slice of the batch is empty only takes part in the gather below)
         eng.sample_loop(x, prep(t, 1), prep(time_info, time_info.shape[-1]), prep(cond, cond.shape[-1]), z_all,
                         betas, alphas, keep=keep, streams=streams, graph=graph)
+    if eng.H == 512:
+        ops.check_rnn_workspaces(d)       # the eight-workgroup form of the sequence kernel: raises if a launch gave up waiting
     if plan.world > 1 and not local_only:
         return plan.all_gather_cat(x)
     return x

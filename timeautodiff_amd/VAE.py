@@ -368,6 +368,11 @@ class VAETrainer:
     def _loss(self, rows, beta):
         """Combine the (all-reduced) partial sums on the host -> python float total."""
         p = self.parts.tolist()
+        # (the read-back above has synchronised: every 16th time also ask whether a sequence launch whose workgroups wait
+        # for each other -- hidden size 512 in bf16 -- gave up waiting)
+        self._n_loss = getattr(self, "_n_loss", 0) + 1
+        if self._n_loss % 16 == 1:
+            ops.check_rnn_workspaces(self.eng.device)
         nc = self.eng.nc
         total, _ = self.eng.total_loss(p[:2 + nc], p[2 + max(nc, 1)], beta, rows)
         return total

@@ -6,6 +6,8 @@ Tensors are float32 with a contiguous last dimension; any leading dimensions
 must collapse to rows of a common stride (slices of a wider buffer are fine)."""
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -465,8 +467,25 @@ def rnn_workspace_bytes(cell, prec, store, B, T, H, ndir):
 
 
 def rnn_ws_status(workspace):
-    """Raises if a launch that used ``workspace`` gave up waiting (synchronises the stream)."""
+    """Raises if a launch that used ``workspace`` gave up waiting (synchronises the stream).  The word it reads stays set
+    until the caller zeroes the workspace."""
     _lib.check(_lib.load().tad_rnn_ws_status(workspace.data_ptr(), _stream()))
+
+
+_RNN_WS = {}      # id -> weak reference: workspaces that launches of rnn_fwd have used (dead ones are dropped at the next check)
+
+
+def check_rnn_workspaces(device=None):
+    """rnn_ws_status for every live workspace a launch has used on ``device`` (default: the current one).  The trainers
+    and the sampler call it where they synchronise anyway: a launch whose workgroups gave up waiting for each other has
+    written results that must not be used."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    for key, ref in list(_RNN_WS.items()):
+        w = ref()
+        if w is None:
+            del _RNN_WS[key]
+        elif w.device.index == dev:
+            rnn_ws_status(w)
 
 
 def rnn_fwd(cell, prec, B, T, H, dirs, workspace=None):
@@ -499,6 +518,7 @@ def rnn_fwd(cell, prec, B, T, H, dirs, workspace=None):
     cost = (2.0 * B * T * nd * G * H * H, float(B * T * nd * H * per_elem))
     if workspace is not None:
         assert workspace.dtype == torch.uint8 and workspace.is_contiguous()
+        _RNN_WS[id(workspace)] = weakref.ref(workspace)
         _call("tad_rnn_fwd_ws", cell, prec, store, B, T, H, nd, arr, workspace.data_ptr(), workspace.numel(), _stream(), cost=cost)
     else:
         _call("tad_rnn_fwd", cell, prec, store, B, T, H, nd, arr, _stream(), cost=cost)
