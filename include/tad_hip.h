@@ -302,6 +302,20 @@ int tad_sampler_tail(int prec, int64_t rows, int D, int K, int H, const float* h
                      const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
                      float c1, float c2, float c3, int last, const float* w_in, const float* b_in, float* xh,
                      int64_t ldxh, tad_stream_t stream);
+
+/* tad_sampler_tail with the step's share of `proj` folded in (DIFF.py:203 and :218 for the next reverse step):
+ * input_proj has K <= 8 inputs, so proj's product over its output, x_h W_1^T, is a K-column product of the updated x
+ * with W_fold = W_1 W_in [H, K] (b_fold = W_1 b_in), which the caller prepares once per call of `sample`.  The row
+ * leaves as relu(x_new W_fold^T + b_fold + vrow + pinv[r]) in bf16: the operand of the LSTM's layer-0 input product
+ * (vrow = the step's row of the i_enc table, pinv = the step-invariant share of proj incl. its bias, row stride
+ * ld_pinv).  One [rows, H] x [H, H] product and one launch fewer per reverse step; rounding differs from the two
+ * products only in that x_h is not rounded to bf16 in between.  prec = TAD_BF16 rounds LayerNorm's output, fc's
+ * weight and the updated x as tad_sampler_tail does; W_fold and b_fold are used as given. */
+int tad_sampler_tail_proj_b16(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
+                              const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
+                              float c1, float c2, float c3, int last, const float* w_fold, const float* b_fold,
+                              const float* vrow, const float* pinv, int64_t ld_pinv, void* pa16, int64_t ldpa,
+                              tad_stream_t stream);
 /* The same launch with the next step's input projection written as bf16 (it feeds `proj`'s product only). */
 int tad_sampler_tail_b16(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
                      const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,

@@ -1079,6 +1079,39 @@ def test_sampler_tail_equals_the_four_launches(ops, dev, prec, shape):
     assert torch.all(xhb._base[:, H:] == 7.0)
 
 
+@pytest.mark.parametrize("rows,Dm,K,H,last", [(300, 400, 6, 200, False), (70, 1024, 6, 512, True), (33, 256, 8, 128, False)])
+def test_sampler_tail_with_folded_proj_share(ops, dev, rows, Dm, K, H, last):
+    """tad_sampler_tail_proj_b16 -- the tail of a reverse step that also leaves relu(x_new (W_1 W_in)^T + W_1 b_in + V[s] +
+    pinv), the LSTM's operand of the NEXT step -- against the two launches it replaces (tad_sampler_tail_b16, then the
+    [rows, H] x [H, H] product with bias, residual and ReLU in its epilogue): the updated x bit for bit, the bf16 operand to
+    two bf16 units in the last place (the unfolded path rounds x_h to bf16 between the two products; the folded one does not)."""
+    rng = np.random.default_rng(8 + H)
+    r = lambda *sh, sc=1.0: D((rng.standard_normal(sh) * sc).astype(np.float32), dev)
+    h = r(rows, Dm, sc=3.0) + 1
+    gamma, beta, fc_w, fc_b = r(Dm), r(Dm), r(K, Dm, sc=0.1), r(K)
+    w_in, b_in, w1 = r(H, K), r(H), r(H, H, sc=H ** -0.5)
+    vrow, pinv = r(H), r(rows, H)
+    x0, z = r(rows, K), r(rows, K)
+    c1, c2, c3 = 1.02, 0.31, 0.2
+    # unfolded: tail -> x_h (bf16) -> product with the rounded W_1
+    xa = x0.clone()
+    xh16 = torch.empty(rows, H, dtype=torch.bfloat16, device=dev)
+    ops.sampler_tail(1, h, gamma, beta, fc_w, fc_b, xa, z, c1, c2, c3, last, w_in, b_in, xh16)
+    ref = torch.relu(xh16.float() @ w1.bfloat16().float().t() + vrow + pinv)
+    # folded: factors rounded as the two products round them, then multiplied in fp32
+    w1r = w1.bfloat16().float()
+    wc = (w1r @ w_in.bfloat16().float()).contiguous()
+    bc = (w1r @ b_in).contiguous()
+    xb = x0.clone()
+    pa16 = torch.full((rows, H + 8), 7.0, dtype=torch.bfloat16, device=dev)[:, :H]
+    ops.sampler_tail_proj(1, h, gamma, beta, fc_w, fc_b, xb, z, c1, c2, c3, last, wc, bc, vrow, pinv, pa16)
+    assert torch.equal(xa, xb)
+    got = pa16.float()
+    assert float((got - ref).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
+    assert float((got - ref).abs().mean()) <= 2.0 ** -9 * float(ref.abs().mean() + 1e-6) * 4
+    assert torch.all(pa16._base[:, H:] == 7.0) and torch.all(got >= 0)
+
+
 # ---------------------------------------------------------------------------- TV-MCG metadata corruption
 @pytest.mark.parametrize("name", ["tvmcg_mixed", "tvmcg_skip"])
 def test_tvmcg_corruption_vs_reference_golden(ops, dev, name):

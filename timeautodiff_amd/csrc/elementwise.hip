@@ -410,9 +410,12 @@ __global__ void sampler_tail_kernel(int64_t rows, int D, int K, int H, int round
                                     const float* __restrict__ fcw, const float* __restrict__ fcb, float* __restrict__ x,
                                     const float* __restrict__ z, float c1, float c2, float c3, int last,
                                     const float* __restrict__ w_in, const float* __restrict__ b_in,
-                                    float* __restrict__ xh, int64_t ldxh, bf16_t* __restrict__ xh16) {
+                                    float* __restrict__ xh, int64_t ldxh, bf16_t* __restrict__ xh16,
+                                    const float* __restrict__ vrow, const float* __restrict__ pinv, int64_t ldp) {
   extern __shared__ float tail_lds[];          // w_in [H, K] (rounded), then b_in [H]
-  for (int e = threadIdx.x; e < H * K; e += blockDim.x) tail_lds[e] = round16 ? (float)(bf16_t)w_in[e] : w_in[e];
+  // pinv != NULL: w_in / b_in are the input projection folded into the x share of `proj` (prepared by the caller from
+  // rounded factors: not rounded again) and the row leaves as relu(. + vrow + pinv[r]), the operand of the LSTM's input side
+  for (int e = threadIdx.x; e < H * K; e += blockDim.x) tail_lds[e] = (round16 && !pinv) ? (float)(bf16_t)w_in[e] : w_in[e];
   for (int e = threadIdx.x; e < H; e += blockDim.x) tail_lds[H * K + e] = b_in[e];
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -485,7 +488,8 @@ __global__ void sampler_tail_kernel(int64_t rows, int D, int K, int H, int round
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
         if (k < K) a += xn[k] * tail_lds[u * K + k];
-      const float o = a + tail_lds[H * K + u];
+      float o = a + tail_lds[H * K + u];
+      if (pinv) o = fmaxf((o + vrow[u]) + pinv[r * ldp + u], 0.f);
       if (xh16) xh16[r * ldxh + u] = (bf16_t)o;            // the next step's `proj` reads it as a bf16 operand
       else xh[r * ldxh + u] = o;
     }
@@ -964,7 +968,8 @@ extern "C" int tad_sampler_update(int64_t n, float* x, const float* pred, const 
 static int sampler_tail(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
                         const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
                         float c1, float c2, float c3, int last, const float* w_in, const float* b_in, float* xh,
-                        int64_t ldxh, bf16_t* xh16, tad_stream_t stream) {
+                        int64_t ldxh, bf16_t* xh16, tad_stream_t stream, const float* vrow = nullptr, const float* pinv = nullptr,
+                        int64_t ldp = 0) {
   TAD_CHECK(rows >= 0 && D > 0 && D <= 1024 && K > 0 && K <= 8 && H > 0 && (int64_t)H * (K + 1) <= 12288,
             "tad_sampler_tail: supported D <= 1024, K <= 8, H*(K+1) <= 12288 (got D=%d K=%d H=%d)", D, K, H);
   TAD_CHECK(h && gamma && beta && fc_w && fc_b && x && z && w_in && b_in && (xh || xh16) && ldh >= D && ldxh >= H, "tad_sampler_tail: bad arguments");
@@ -974,7 +979,7 @@ static int sampler_tail(int prec, int64_t rows, int D, int K, int H, const float
   const int nc = (int)cdiv64(D, 64);
   const size_t lds = sizeof(float) * (size_t)H * (K + 1);
   const int r16 = prec == TAD_BF16 ? 1 : 0;
-#define TAIL(NC) hipLaunchKernelGGL((sampler_tail_kernel<NC, 8>), dim3((unsigned)g), dim3(EW_BLOCK), lds, EW_STREAM, rows, D, K, H, r16, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, c1, c2, c3, last, w_in, b_in, xh, ldxh, xh16)
+#define TAIL(NC) hipLaunchKernelGGL((sampler_tail_kernel<NC, 8>), dim3((unsigned)g), dim3(EW_BLOCK), lds, EW_STREAM, rows, D, K, H, r16, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, c1, c2, c3, last, w_in, b_in, xh, ldxh, xh16, vrow, pinv, ldp)
   if (nc <= 2) TAIL(2);
   else if (nc <= 8) TAIL(8);
   else TAIL(16);
@@ -996,6 +1001,16 @@ extern "C" int tad_sampler_tail_b16(int prec, int64_t rows, int D, int K, int H,
                                     int64_t ldxh, tad_stream_t stream) {
   return sampler_tail(prec, rows, D, K, H, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, c1, c2, c3, last, w_in, b_in, nullptr, ldxh,
                       reinterpret_cast<bf16_t*>(xh16), stream);
+}
+
+extern "C" int tad_sampler_tail_proj_b16(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
+                                         const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
+                                         float c1, float c2, float c3, int last, const float* w_fold, const float* b_fold,
+                                         const float* vrow, const float* pinv, int64_t ld_pinv, void* pa16, int64_t ldpa,
+                                         tad_stream_t stream) {
+  TAD_CHECK(vrow && pinv && ld_pinv >= H && pa16, "tad_sampler_tail_proj_b16: bad arguments");
+  return sampler_tail(prec, rows, D, K, H, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, c1, c2, c3, last, w_fold, b_fold, nullptr, ldpa,
+                      reinterpret_cast<bf16_t*>(pa16), stream, vrow, pinv, ld_pinv);
 }
 
 extern "C" int tad_mse_loss(int64_t n, const float* pred, const float* target, float grad_scale, float* dpred,

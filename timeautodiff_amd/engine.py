@@ -20,6 +20,8 @@ GRAD_STREAM = os.environ.get("TAD_GRAD_STREAM", "0") != "0"
 SAMPLE_STREAMS = int(os.environ.get("TAD_SAMPLE_STREAMS", "2"))
 # TAD_SAMPLE_FUSED_TAIL=0: LayerNorm, fc, the sampler update and the next input_proj as four launches instead of one
 SAMPLE_FUSED_TAIL = os.environ.get("TAD_SAMPLE_FUSED_TAIL", "1") != "0"
+# the x share of `proj` folded into the tail of the previous reverse step (bf16 mode): one product and one launch fewer per step
+SAMPLE_FOLD = os.environ.get("TAD_SAMPLE_FOLD", "1") != "0"
 # TAD_SAMPLE_GRAPH=1: replay the reverse loop as one captured HIP graph per batch shape instead of enqueueing it kernel
 # by kernel (off by default: at 1k sequences the loop is device-bound and the graph measured no faster)
 SAMPLE_GRAPH = os.environ.get("TAD_SAMPLE_GRAPH", "0") == "1"
@@ -1248,8 +1250,23 @@ class DenoiserEngine:
             xh16 = ws.get("s.xh16", (BT, H), dtype=torch.bfloat16)
             pa16 = ws.get("s.pa16", (BT, H), dtype=torch.bfloat16)
             ops.cvt_bf16(xh, xh16)
+        # input_proj has K inputs: its output's share of `proj`, x_h W_1^T, is the K-column product x (W_1 W_in)^T + W_1 b_in.
+        # The tail of every step then leaves relu(that + V[s] + pinv) behind -- the LSTM's operand -- and the step's
+        # [BT, H] x [H, H] product is gone (reference DIFF.py:203, 218).  Factors rounded to bf16 as the two products round them.
+        fold = b16 and SAMPLE_FOLD
+        wc = bc = None
+        if fold:
+            w1r = wp[:, :H].to(torch.bfloat16).float().contiguous()
+            win_t = torch.cat([fp.p("input_proj.net.0.weight").to(torch.bfloat16).float().t(),
+                               fp.p("input_proj.net.0.bias").view(1, H)], 0).contiguous()            # [K + 1, H]
+            wcb = ws.get("s.wfold", (H, K + 1))
+            ops.linear_fwd(F32, w1r, win_t, None, wcb)
+            wc, bc = wcb[:, :K].contiguous(), wcb[:, K].contiguous()
+            # the first step's operand the long way round
+            ops.mm16_nt(xh16, self.im["proj_x"]["fwd"], V[S - 1], pa16, act=ACT_RELU, residual=pinv)
         return dict(x2=x2, B=B, T=T, ws=ws, pinv=pinv, V=V, wp=wp, z=z_all, xh=xh, pa=ws.get("pa", (BT, H)),
-                    ln=ws.get("ln", (BT, 2 * H)), pred=ws.get("pred", (BT, K)), fused=fused, b16=b16, xh16=xh16, pa16=pa16)
+                    ln=ws.get("ln", (BT, 2 * H)), pred=ws.get("pred", (BT, K)), fused=fused, b16=b16, xh16=xh16, pa16=pa16,
+                    fold=fold, wc=wc, bc=bc)
 
     def _step_noise(self, st, s):
         """Noise of reverse step s for the state's sequences: a row of the staged tensor, or drawn now."""
@@ -1265,6 +1282,12 @@ class DenoiserEngine:
         fp, prec, H = self.fp, self.prec, self.H
         x2, xh, pa, ln, pred = st["x2"], st["xh"], st["pa"], st["ln"], st["pred"]
         zs = self._step_noise(st, s)
+        if st["fold"]:
+            lout = self.lstm.forward(st["pa16"], st["B"], st["T"], st["ws"], "lstm", False)
+            ops.sampler_tail_proj(prec, lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), fp.p("fc.weight"), fp.p("fc.bias"),
+                                  x2, zs, coef[0][s], coef[1][s], coef[2][s], s == 0, st["wc"], st["bc"], st["V"][max(s - 1, 0)],
+                                  st["pinv"], st["pa16"])
+            return
         if st["b16"]:
             ops.mm16_nt(st["xh16"], self.im["proj_x"]["fwd"], st["V"][s], st["pa16"], act=ACT_RELU, residual=st["pinv"])
             lout = self.lstm.forward(st["pa16"], st["B"], st["T"], st["ws"], "lstm", False)

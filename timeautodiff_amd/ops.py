@@ -781,6 +781,21 @@ def sampler_tail(prec, h, gamma, beta, fc_w, fc_b, x, z, c1, c2, c3, last, w_in,
           _ptr(z), float(c1), float(c2), float(c3), int(bool(last)), _ptr(w_in), _ptr(b_in), xp, ldxh, _stream())
 
 
+def sampler_tail_proj(prec, h, gamma, beta, fc_w, fc_b, x, z, c1, c2, c3, last, w_fold, b_fold, vrow, pinv, pa16, eps=1e-5):
+    """sampler_tail with the next step's x share of `proj` folded in: pa16 = relu(x_new w_fold^T + b_fold + vrow + pinv)
+    as bfloat16 (reference DIFF.py:221-223, 348-351, then 203 and 218 of the next reverse step)."""
+    hp, rows, D, ldh = as2d(h)
+    pp, rows2, H, ldpa = as2d(pa16, torch.bfloat16)
+    ip, rows3, H3, ldp = as2d(pinv)
+    K = fc_w.shape[0]
+    assert rows == rows2 == rows3 and H3 == H and fc_w.shape == (K, D) and w_fold.shape == (H, K) and fc_w.is_contiguous()
+    assert w_fold.is_contiguous() and b_fold.numel() == H and vrow.numel() == H and vrow.is_contiguous()
+    assert x.is_contiguous() and z.is_contiguous() and x.numel() == rows * K and z.numel() == rows * K
+    _call("tad_sampler_tail_proj_b16", prec, rows, D, K, H, hp, ldh, _ptr(gamma), _ptr(beta), float(eps), _ptr(fc_w), _ptr(fc_b),
+          _ptr(x), _ptr(z), float(c1), float(c2), float(c3), int(bool(last)), _ptr(w_fold), _ptr(b_fold), _ptr(vrow), ip, ldp, pp, ldpa,
+          _stream())
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n
