@@ -14,7 +14,7 @@ def main():
     prec = ops.BF16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else ops.F32
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     sdt = torch.bfloat16 if (prec == ops.BF16 and (len(sys.argv) < 4 or sys.argv[3] == "bf16")) else torch.float32
-    T, H, nd = 24, 200, 2
+    T, H, nd = int(os.environ.get("RNN_T", "24")), int(os.environ.get("RNN_H", "200")), 2      # (environment: other shapes)
     dev = torch.device("cuda:0")
     for cell, G in ((0, 4), (1, 3)):
         xproj = torch.randn(B * T, nd * 4 * H, device=dev).to(sdt)

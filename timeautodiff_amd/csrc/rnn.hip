@@ -796,7 +796,10 @@ template <int CELL, bool BF16, bool ST16, int JPW, bool PHASED, int NKR = 0>
 __global__ __launch_bounds__(512) void rnn_bwd_kernel(RnnBwdArgs a) {
   static_assert(NKR == 0 || (BF16 && JPW == 1 && !PHASED), "register-resident k-blocks: one-pass bf16 form, one chunk per wave");
   constexpr int G = CELL == TAD_CELL_LSTM ? 4 : 3;
-  constexpr int PF = BF16 ? 4 : 2;
+  // k-blocks of the transposed W_hh image a wave keeps in flight from L2 (4 VGPRs each).  With two chunks per wave (H = 512:
+  // everything is streamed, 1.5-2 MB per step) six measured 4-5 % faster than four (two: 28 % slower; eight: as six, with
+  // spills); with one chunk per wave (H = 200: most of the image is resident) six cost the GRU 10 %.
+  constexpr int PF = BF16 ? (JPW > 1 ? 6 : 4) : 2;
   typedef Slots<ST16> SL;
   typedef typename SL::raw raw_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
