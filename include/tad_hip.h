@@ -86,6 +86,9 @@ int tad_linear_bwd_weight(int prec, int64_t M, int64_t N, int64_t K, const float
  * pre-activations, their gradients and the weight images live in HBM as bf16.  bf16
  * operands need 16-byte aligned rows, leading dimensions and extents that are multiples of 8.
  *   fwd_b16:        Y = act(X W16^T + bias), X fp32, W16 bf16 [N,K], Y fp32 or bf16 (y_dtype);
+ *   fwd_b16x:       the same with X16 stored as bf16 too, through the square-tiled kernel: for weights too large for
+ *                   tad_mm16_nt's scheme, in which every workgroup streams the whole weight (the input side of a
+ *                   recurrent layer at hidden size 512: 4096 x 1024);
  *   bwd_data_b16:   dX = dY16 W16 (+ dX) with the ReLU mask, dY16 bf16 [M,N], W16 bf16 [N,K], dX fp32;
  *   bwd_data_b16o:  the same product with a bf16 result dX16 and a bf16 mask operand (no accumulate): for a dX
  *                   that only matrix products read (dX16, relu_of16: 16-byte aligned, ld multiples of 4);
@@ -93,6 +96,8 @@ int tad_linear_bwd_weight(int prec, int64_t M, int64_t N, int64_t K, const float
  *                   sums are taken over the bf16 values of dY16. */
 int tad_linear_fwd_b16(int64_t M, int64_t N, int64_t K, const float* X, int64_t ldx, const void* W16, int64_t ldw,
                        const float* bias, void* Y, int y_dtype, int64_t ldy, int act, tad_stream_t stream);
+int tad_linear_fwd_b16x(int64_t M, int64_t N, int64_t K, const void* X16, int64_t ldx, const void* W16, int64_t ldw,
+                        const float* bias, void* Y, int y_dtype, int64_t ldy, int act, tad_stream_t stream);
 int tad_linear_bwd_data_b16(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const void* W16,
                             int64_t ldw, float* dX, int64_t ldx, const float* relu_of, int64_t ld_relu,
                             int accumulate, tad_stream_t stream);

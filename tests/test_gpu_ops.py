@@ -169,6 +169,16 @@ def test_linear_b16_family(ops, dev, M, N, K):
     # (plus the fp32 accumulation noise of the unrounded sum, which matters where the terms cancel)
     assert np.all(np.abs(got - want) <= np.abs(want) * 2.0 ** -8 + 1e-5 * np.abs(want).max())
     assert float(Y16[:, N:].float().abs().max()) == 0.0
+    # the same forward with the input stored as bf16 too (a strided weight view, as the engine passes its padded images)
+    X16 = torch.from_numpy(X).bfloat16().to(dev)
+    Wpad = torch.zeros(N + 3, K + 8, dtype=torch.bfloat16, device=dev)
+    Wpad[:N, :K] = Wd
+    Yx = torch.zeros(M, N + 8, device=dev)
+    ops.linear_fwd_b16x(X16, Wpad[:N, :K], D(b, dev), Yx[:, :N])
+    assert fu.rel_err(Yx[:, :N].cpu().numpy(), ref) < F32_TOL and float(Yx[:, N:].abs().max()) == 0.0
+    Yx16 = torch.zeros(M, N + 8, dtype=torch.bfloat16, device=dev)
+    ops.linear_fwd_b16x(X16, Wpad[:N, :K], D(b, dev), Yx16[:, :N], act=ops.ACT_RELU)
+    assert torch.equal(Yx16, Y16)
     # backward wrt the input: bf16 gradient x bf16 weights
     dY16 = torch.from_numpy(rnd(rng, M, N)).bfloat16().to(dev)
     dYf = dY16.float().cpu().numpy().astype(np.float64)

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "tad_linear_bwd_data": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "tad_linear_bwd_weight": (_i, [_i, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, C.POINTER(C.c_int32), _p]),
     "tad_linear_fwd_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i, _i64, _i, _p]),
+    "tad_linear_fwd_b16x": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i, _i64, _i, _p]),
     "tad_linear_bwd_data_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "tad_linear_bwd_data_b16o": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p]),
     "tad_linear_bwd_weight_b16": (_i, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, C.POINTER(C.c_int32), _p]),

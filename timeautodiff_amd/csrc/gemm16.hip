@@ -28,6 +28,27 @@ extern "C" int tad_linear_fwd_b16(int64_t M, int64_t N, int64_t K, const float* 
   return launch_bf16<KC32, KC16>(pick_cfg(TAD_BF16, M, N, MIN_WGS), p, 1, (hipStream_t)stream);
 }
 
+extern "C" int tad_linear_fwd_b16x(int64_t M, int64_t N, int64_t K, const void* X16, int64_t ldx, const void* W16, int64_t ldw,
+                                   const float* bias, void* Y, int y_dtype, int64_t ldy, int act, tad_stream_t stream) {
+  TAD_CHECK(M >= 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N, "tad_linear_fwd_b16x: bad shape M=%ld N=%ld K=%ld",
+            (long)M, (long)N, (long)K);
+  TAD_CHECK(X16 && W16 && Y, "tad_linear_fwd_b16x: null pointer");
+  TAD_CHECK(ldx < LD_MAX && ldw < LD_MAX && ldy < LD_MAX, "tad_linear_fwd_b16x: leading dimension too large");
+  TAD_CHECK(act == TAD_ACT_NONE || act == TAD_ACT_RELU, "tad_linear_fwd_b16x: bad act %d", act);
+  TAD_CHECK(y_dtype == TAD_F32 || y_dtype == TAD_BF16, "tad_linear_fwd_b16x: bad y_dtype %d", y_dtype);
+  TAD_CHECK(rows16(X16, ldx) && rows16(W16, ldw) && K % 8 == 0,
+            "tad_linear_fwd_b16x: X16 and W16 need 16-byte aligned rows (ld %% 8 == 0) and K %% 8 == 0");
+  if (M == 0) return TAD_OK;
+  GemmParams p{};
+  p.A = X16; p.sa_row = ldx; p.sa_k = 1;
+  p.B = W16; p.sb_row = ldw; p.sb_k = 1;
+  p.C = Y; p.ldc = ldy; p.c16 = y_dtype == TAD_BF16; p.M = M; p.N = N; p.K = K;
+  p.bias = bias; p.act = act;
+  p.k_per_split = cdiv64(K, BK) * BK;
+  TAD_CHECK(!p.c16 || wide_epilogue_ok(p), "tad_linear_fwd_b16x: a bf16 Y needs N %% 4 == 0, ldy %% 4 == 0 and 16-byte aligned Y and bias");
+  return launch_bf16<KC16, KC16>(pick_cfg(TAD_BF16, M, N, MIN_WGS), p, 1, (hipStream_t)stream);
+}
+
 extern "C" int tad_linear_bwd_data_b16(int64_t M, int64_t N, int64_t K, const void* dY16, int64_t ldy, const void* W16,
                                        int64_t ldw, float* dX, int64_t ldx, const float* relu_of, int64_t ld_relu,
                                        int accumulate, tad_stream_t stream) {

@@ -22,6 +22,8 @@ SAMPLE_STREAMS = int(os.environ.get("TAD_SAMPLE_STREAMS", "2"))
 SAMPLE_FUSED_TAIL = os.environ.get("TAD_SAMPLE_FUSED_TAIL", "1") != "0"
 # the x share of `proj` folded into the tail of the previous reverse step (bf16 mode): one product and one launch fewer per step
 SAMPLE_FOLD = os.environ.get("TAD_SAMPLE_FOLD", "1") != "0"
+# input-side products of a recurrent layer whose weight has at least this many elements take the square-tiled kernel
+XPROJ_TILED_MIN = int(os.environ.get("TAD_XPROJ_TILED_MIN", str(1 << 21)))
 # TAD_SAMPLE_GRAPH=1: replay the reverse loop as one captured HIP graph per batch shape instead of enqueueing it kernel
 # by kernel (off by default: at 1k sequences the loop is device-bound and the graph measured no faster)
 SAMPLE_GRAPH = os.environ.get("TAD_SAMPLE_GRAPH", "0") == "1"
@@ -454,7 +456,13 @@ class RnnStack:
         uf = self.G / 4.0           # a GRU's fourth slot is structural padding (zero weights)
         if x.dtype == torch.bfloat16:
             assert self.mm16[layer]
-            ops.mm16_nt(x, w_gl, bias_gl, xproj, useful=uf)
+            n, k = xproj.shape[1], x.shape[1]
+            if n * k >= XPROJ_TILED_MIN:
+                # a weight of megabytes (hidden size 512: 4096 x 1024): mm16_nt would stream all of it through every
+                # workgroup's LDS ring; the square-tiled kernel re-reads a 256-row panel of it per tile instead
+                ops.linear_fwd_b16x(x, w_gl[:n, :k], bias_gl, xproj, useful=uf)
+            else:
+                ops.mm16_nt(x, w_gl, bias_gl, xproj, useful=uf)
         elif self.store[layer] == torch.bfloat16:
             ops.linear_fwd_b16(x, w_gl[:xproj.shape[1], :x.shape[1]], bias_gl, xproj, useful=uf)
         else:

@@ -256,6 +256,17 @@ def linear_fwd_b16(x, w16, bias, y, act=ACT_NONE, useful=1.0):
           act, _stream(), cost=_cost(2.0 * M * N * K, 4.0 * M * K + 2.0 * N * K + y.element_size() * M * N, useful))
 
 
+def linear_fwd_b16x(x16, w16, bias, y, act=ACT_NONE, useful=1.0):
+    """y = act(x16 w16^T + bias): x16 bfloat16 [M,K], w16 bfloat16 [N,K] (any row stride that is a multiple of 8), y float32 or
+    bfloat16; the square-tiled kernel, for weights too large for mm16_nt's scheme."""
+    xp, M, K, ldx = as2d(x16, torch.bfloat16)
+    wp, N, Kw, ldw = as2d(w16, torch.bfloat16)
+    yp, My, Ny, ldy = as2d(y, y.dtype)
+    assert K == Kw and M == My and N == Ny, (x16.shape, w16.shape, y.shape)
+    _call("tad_linear_fwd_b16x", M, N, K, xp, ldx, wp, ldw, _ptr(bias), yp, BF16 if y.dtype == torch.bfloat16 else F32, ldy,
+          act, _stream(), cost=_cost(2.0 * M * N * K, 2.0 * M * K + 2.0 * N * K + y.element_size() * M * N, useful))
+
+
 def linear_bwd_data_b16(dy16, w16, dx, relu_of=None, accumulate=False, useful=1.0):
     """dx = dy16 w16 (+ dx), masked where relu_of <= 0: dy16 bfloat16 [M,N], w16 bfloat16 [N,K], dx fp32."""
     dyp, M, N, ldy = as2d(dy16, torch.bfloat16)
