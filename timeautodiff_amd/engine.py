@@ -22,6 +22,8 @@ SAMPLE_STREAMS = int(os.environ.get("TAD_SAMPLE_STREAMS", "2"))
 SAMPLE_FUSED_TAIL = os.environ.get("TAD_SAMPLE_FUSED_TAIL", "1") != "0"
 # the x share of `proj` folded into the tail of the previous reverse step (bf16 mode): one product and one launch fewer per step
 SAMPLE_FOLD = os.environ.get("TAD_SAMPLE_FOLD", "1") != "0"
+# the denoiser keeps its product-only tensors as bf16 up to this 4 H (products with K > 1024 take the square-tiled kernel)
+MM16_MAX_4H = int(os.environ.get("TAD_MM16_MAX_4H", "4096"))
 # input-side products of a recurrent layer whose weight has at least this many elements take the square-tiled kernel
 XPROJ_TILED_MIN = int(os.environ.get("TAD_XPROJ_TILED_MIN", str(1 << 21)))
 # TAD_SAMPLE_GRAPH=1: replay the reverse loop as one captured HIP graph per batch shape instead of enqueueing it kernel
@@ -868,7 +870,7 @@ class DenoiserEngine:
         self.imgs = W16Images(self.fp)
         self.emb.use_mm16(self.imgs)
         # the training step keeps what only matrix products read as bfloat16 when every width involved is a multiple of 8
-        self.mm16 = bool(MM16 and self.prec == BF16 and self.H % 8 == 0 and 4 * self.H <= 1024 and self.emb.mm16 and self.emb.last16
+        self.mm16 = bool(MM16 and self.prec == BF16 and self.H % 8 == 0 and 4 * self.H <= MM16_MAX_4H and self.emb.mm16 and self.emb.last16
                          and all(self.gru.mm16) and all(self.lstm.mm16))
         if self.mm16:
             p_ = self.fp.p

@@ -311,6 +311,9 @@ def w16_image(n, k, device):
     return torch.zeros(-(-n // 64) * 64, -(-k // 128) * 128, dtype=torch.bfloat16, device=device)
 
 
+MM16_NT_MAX_K = 1024        # tad_mm16_nt keeps a wave's 32 rows of A in registers: K at most 1024
+
+
 def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=None, useful=1.0):
     """c = act(a16 w16[:N, :K]^T + bias + residual), zeroed where relu_of <= 0 (act=ACT_DSILU: multiplied by silu'(relu_of) instead): a16 [M,K] bfloat16, w16 a padded
     bfloat16 weight image (``w16_image``: rows >= N rounded up to 64, columns K rounded up to 128, zeros beyond K),
@@ -320,6 +323,11 @@ def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=
     cp, Mc, N, ldc = as2d(c, c.dtype)
     wp, Nw, Kw, ldw = as2d(w16, torch.bfloat16)
     assert M == Mc and Nw >= -(-N // 64) * 64 and Kw >= -(-K // 128) * 128 and Kw - K < 128, (a16.shape, w16.shape, c.shape)
+    if K > MM16_NT_MAX_K:
+        # more of A than a wave keeps in registers (proj and cond_output + input_proj at hidden size 512): the square-tiled
+        # kernel on the same operands, for the plain epilogues it has
+        assert residual is None and relu_of is None and z_out is None and act in (ACT_NONE, ACT_RELU), "mm16_nt: K > 1024 with a fused operand"
+        return linear_fwd_b16x(a16, w16[:N, :K], bias, c, act=act, useful=useful)
     rp = ldr = up = ldu = zp = ldz = 0
     rdt = udt = F32
     if residual is not None:
