@@ -383,7 +383,7 @@ int tad_silu_bwd_b16(int64_t n, const float* z, const float* da, void* dz16, tad
 
 /* `layer_norm` + `fc` of BiRNN_score.forward (DIFF.py:221-223) in one pass over the recurrent output: LayerNorm of
  * a row (eps 1e-5; mean_rstd[r] = {mean, rstd} for the backward), then pred[r, :] = fc_w [K, D] applied to it + fc_b
- * (K <= 8, D <= 512).  The normalised row is written only if y != NULL.  prec = TAD_BF16 rounds the projection's
+ * (K <= 8, D <= 1024).  The normalised row is written only if y != NULL.  prec = TAD_BF16 rounds the projection's
  * operands to bf16 like the matrix kernels do. */
 int tad_ln_fc_fwd(int prec, int64_t rows, int D, int K, const float* x, int64_t ldx, const float* gamma, const float* beta,
                   float eps, const float* fc_w, const float* fc_b, float* y, int64_t ldy, float* mean_rstd, float* pred,

@@ -1219,7 +1219,7 @@ def test_grad_norm_sq(ops, dev, n):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("rows,D,K", [(7, 48, 6), (1000, 400, 6), (333, 400, 8), (64, 130, 3)])
+@pytest.mark.parametrize("rows,D,K", [(7, 48, 6), (1000, 400, 6), (333, 400, 8), (64, 130, 3), (700, 1024, 6), (90, 600, 8)])
 def test_ln_fc_fused_equals_the_separate_launches(ops, dev, prec, rows, D, K):
     """LayerNorm + narrow projection in one launch, forward and backward, against layernorm_fwd/bwd + the linear family
     (the same arithmetic per element; the sums of the gradients take another order: 1e-5 fp32; bf16 mode rounds the

@@ -1268,7 +1268,7 @@ extern "C" int tad_layernorm_bwd(int64_t rows, int D, const float* dy, int64_t l
 extern "C" int tad_ln_fc_fwd(int prec, int64_t rows, int D, int K, const float* x, int64_t ldx, const float* gamma, const float* beta,
                              float eps, const float* fc_w, const float* fc_b, float* y, int64_t ldy, float* mean_rstd, float* pred,
                              tad_stream_t stream) {
-  TAD_CHECK(rows >= 0 && D > 0 && D <= 512 && K > 0 && K <= 8, "tad_ln_fc_fwd: supported D <= 512, K <= 8 (got D=%d K=%d)", D, K);
+  TAD_CHECK(rows >= 0 && D > 0 && D <= 1024 && K > 0 && K <= 8, "tad_ln_fc_fwd: supported D <= 1024, K <= 8 (got D=%d K=%d)", D, K);
   TAD_CHECK(x && gamma && beta && fc_w && fc_b && mean_rstd && pred && ldx >= D && (!y || ldy >= D), "tad_ln_fc_fwd: bad arguments");
   if (rows == 0) return TAD_OK;
   int64_t g = cdiv64(rows, EW_BLOCK / 64);
@@ -1277,7 +1277,8 @@ extern "C" int tad_ln_fc_fwd(int prec, int64_t rows, int D, int K, const float* 
 #define LNFC(NC) hipLaunchKernelGGL((ln_fc_fwd_kernel<NC, 8>), dim3((unsigned)g), dim3(EW_BLOCK), 0, EW_STREAM, rows, D, K, r16, x, ldx, gamma, beta, eps, fc_w, fc_b, y, ldy, mean_rstd, pred)
   if (D <= 128) LNFC(2);
   else if (D > 384 && D <= 448) LNFC(7);      // 2H = 400 of the bench: 7 columns per lane, not 8
-  else LNFC(8);
+  else if (D <= 512) LNFC(8);
+  else LNFC(16);                              // 2H = 1024 (hidden size 512): one wave per SIMD, the next row in flight
 #undef LNFC
   TAD_LAUNCH_CHECK();
   return TAD_OK;
@@ -1286,7 +1287,7 @@ extern "C" int tad_ln_fc_fwd(int prec, int64_t rows, int D, int K, const float* 
 extern "C" int tad_ln_fc_bwd(int prec, int64_t rows, int D, int K, const float* dpred, const float* x, int64_t ldx, const float* gamma,
                              const float* beta, const float* mean_rstd, const float* fc_w, float* dx, int64_t lddx, float* dgamma,
                              float* dbeta, float* dfc_w, float* dfc_b, tad_stream_t stream) {
-  TAD_CHECK(rows >= 0 && D > 0 && D <= 512 && K > 0 && K <= 8, "tad_ln_fc_bwd: supported D <= 512, K <= 8 (got D=%d K=%d)", D, K);
+  TAD_CHECK(rows >= 0 && D > 0 && D <= 1024 && K > 0 && K <= 8, "tad_ln_fc_bwd: supported D <= 1024, K <= 8 (got D=%d K=%d)", D, K);
   TAD_CHECK(dpred && x && gamma && beta && mean_rstd && fc_w && dx && dgamma && dbeta && dfc_w && dfc_b && ldx >= D && lddx >= D,
             "tad_ln_fc_bwd: bad arguments");
   if (rows == 0) return TAD_OK;
@@ -1306,7 +1307,8 @@ extern "C" int tad_ln_fc_bwd(int prec, int64_t rows, int D, int K, const float* 
 #define LNFC(NC, DWV, G, NAV) hipLaunchKernelGGL((ln_fc_bwd_kernel<NC, 8, DWV>), dim3((unsigned)(G)), dim3(EW_BLOCK), sizeof(float) * (NAV) * NC * 64, EW_STREAM, rows, D, K, r16, dpred, x, ldx, gamma, beta, mean_rstd, fc_w, dx, lddx, dgamma, dbeta, dfc_w, dfc_b)
   if (D <= 128) { LNFC(2, false, g, 2); LNFC(2, true, g2, 8); }
   else if (D > 384 && D <= 448) { LNFC(7, false, g, 2); LNFC(7, true, g2, 8); }
-  else { LNFC(8, false, g, 2); LNFC(8, true, g2, 8); }
+  else if (D <= 512) { LNFC(8, false, g, 2); LNFC(8, true, g2, 8); }
+  else { LNFC(16, false, g, 2); LNFC(16, true, g2, 8); }
 #undef LNFC
   TAD_LAUNCH_CHECK();
   return TAD_OK;

@@ -5,6 +5,7 @@ stream; every wrapper enqueues hand-written gfx950 kernels on that stream.
 Tensors are float32 with a contiguous last dimension; any leading dimensions
 must collapse to rows of a common stride (slices of a wider buffer are fine)."""
 import ctypes as C
+import os
 
 import weakref
 
@@ -311,6 +312,7 @@ def w16_image(n, k, device):
     return torch.zeros(-(-n // 64) * 64, -(-k // 128) * 128, dtype=torch.bfloat16, device=device)
 
 
+LN_FC_MAX_D = int(os.environ.get("TAD_LN_FC_MAX_D", "1024"))     # widest row of the fused LayerNorm + fc launches (experiments: 512)
 MM16_NT_MAX_K = 1024        # tad_mm16_nt keeps a wave's 32 rows of A in registers: K at most 1024
 
 
@@ -648,7 +650,7 @@ def layernorm_fwd(x, gamma, beta, y, mean_rstd, eps=1e-5):
 
 
 def ln_fc_supported(D, K):
-    return D <= 512 and K <= 8
+    return D <= LN_FC_MAX_D and K <= 8
 
 
 def ln_fc_fwd(prec, x, gamma, beta, fc_w, fc_b, mean_rstd, pred, y=None, eps=1e-5):
