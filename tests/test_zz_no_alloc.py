@@ -65,3 +65,32 @@ def test_metadata_noise_static_rejects_oversize_and_empty(lib):
     rc = lib.tad_metadata_noise_static(0, 80, 3, cols, cond.data_ptr(), 80, noise.data_ptr(), 0.5, out.data_ptr(), 80,
                                        torch.cuda.current_stream().cuda_stream)
     assert rc == 0
+
+
+def test_metadata_noise_static_replayed_from_a_graph(lib):
+    """The callers this entry point is for include code under graph capture: captured once and replayed between other work
+    of the process (fills, small copies), every replay gives the result of a direct call (the statistics are cleared by a
+    kernel of the library: a memset node was seen to write other values than the captured zero on replay)."""
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    rng = np.random.default_rng(3)
+    rows, F, cols, level = 24 * 200, 28, [3, 9, 27, 0, 14], 0.3
+    cond = torch.from_numpy((rng.standard_normal((rows, F)) * rng.uniform(0.1, 5.0, F)).astype(np.float32)).to(dev)
+    noise = torch.from_numpy(rng.standard_normal((rows, len(cols))).astype(np.float32)).to(dev)
+    ref = _run(lib, "tad_metadata_noise_static", cond, cols, noise, level)
+    out = torch.empty_like(cond)
+    carr = (C.c_int32 * len(cols))(*cols)
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(g, stream=cap):
+            rc = lib.tad_metadata_noise_static(rows, F, len(cols), carr, cond.data_ptr(), cond.stride(0), noise.data_ptr(), float(level),
+                                               out.data_ptr(), out.stride(0), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.tad_last_error().decode()
+    for rep in range(8):
+        assert int((cond > 0.2 * rep).nonzero().shape[0]) > 0
+        out.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=2e-7, atol=1e-7)

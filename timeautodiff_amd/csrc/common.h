@@ -34,6 +34,22 @@ void tad_note_kernel(const char* fmt, ...);   // records the launched kernel's n
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Device words that a launch of this library needs to find zero (arrival counters, sums that atomics add to) are zeroed by
+// this kernel and not by hipMemsetAsync.  Under stream capture the memset becomes a memset node, and replays of such a node
+// were seen to fill the words with other values than the one captured (ROCm 7.2, the graph replayed from a process that
+// had run other fills and small copies since the capture): counters of the replayed launch then started at arbitrary
+// values.  A kernel node carries its arguments with it.  bytes: a multiple of 4, from a 4-byte-aligned address.
+static __global__ void tad_zero_words_kernel(uint32_t* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static inline hipError_t tad_zero_async(void* p, size_t bytes, hipStream_t s) {
+  const size_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(tad_zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), n);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // device math
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -1383,7 +1383,7 @@ extern "C" int tad_enc_grad_b16(int64_t M, int N, const void* g16, int64_t ldg, 
   TAD_CHECK((reinterpret_cast<uintptr_t>(g16) & 15) == 0, "tad_enc_grad_b16: g16 must be 16-byte aligned");
   TAD_CHECK(L > 0 && col1 >= 0 && col2 >= 0 && col1 + L <= ldw && col2 + L <= ldw, "tad_enc_grad_b16: column ranges outside W");
   if (M == 0) return TAD_OK;
-  if (hipMemsetAsync(sums, 0, (size_t)3 * N * sizeof(float), EW_STREAM) != hipSuccess) { tad_set_error("tad_enc_grad_b16: memset failed"); return TAD_ERR_LAUNCH; }
+  if (tad_zero_async(sums, (size_t)3 * N * sizeof(float), EW_STREAM) != hipSuccess) { tad_set_error("tad_enc_grad_b16: zeroing the sums failed"); return TAD_ERR_LAUNCH; }
   const int lpr = N <= 64 ? 8 : N <= 128 ? 16 : N <= 256 ? 32 : 64;
   const int rpw = 64 / lpr;
   int64_t wgs = cdiv64(M, (int64_t)4 * rpw * 4);          // at least four row groups per wave

@@ -23,7 +23,7 @@
 // lane adds 1 to the quarter's arrival counter (agent scope).  A consumer polls that counter with sc1 loads from one lane
 // until it reaches 8 x (publishes so far), passes a workgroup barrier, and reads the eight slices with sc1 loads
 // (they bypass the CU's L1, which other CUs' stores never refresh).  Counters only grow within a launch and are
-// zeroed by a memset in front of it.  Every wait is bounded: a wait that runs out sets the workspace's status word and
+// zeroed by a small kernel in front of it (tad_zero_async).  Every wait is bounded: a wait that runs out sets the workspace's status word and
 // the workgroup leaves, so a launch whose workgroups cannot all be resident ends instead of hanging.
 #include "common.h"
 #include "rnn_layout.h"
@@ -410,8 +410,8 @@ int launch_cluster(ClArgs a, hipStream_t s) {
   const int max_slots = cl_max_slots(reinterpret_cast<const void*>(k));
   if (max_slots <= 0) { tad_set_error("tad_rnn_fwd_ws: no room for a group of %d workgroups on this device", CL_NC); return TAD_ERR_LAUNCH; }
   a.nslots = a.nitems < max_slots ? a.nitems : max_slots;
-  hipError_t e = hipMemsetAsync(a.ctr, 0, CL_CTR_BYTES, s);
-  if (e != hipSuccess) { tad_set_error("tad_rnn_fwd_ws: hipMemsetAsync failed: %s", hipGetErrorString(e)); return TAD_ERR_LAUNCH; }
+  hipError_t e = tad_zero_async(a.ctr, CL_CTR_BYTES, s);
+  if (e != hipSuccess) { tad_set_error("tad_rnn_fwd_ws: zeroing the counters failed: %s", hipGetErrorString(e)); return TAD_ERR_LAUNCH; }
   hipLaunchKernelGGL(k, dim3((unsigned)(a.nslots * CL_NC)), dim3(512), CL_LDS_BYTES, s, a);
   TAD_LAUNCH_CHECK();
   tad_note_kernel("rnn_cluster_fwd_kernel<%d, %s>", CELL, STASH ? "true" : "false");

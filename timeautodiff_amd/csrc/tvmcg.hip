@@ -124,8 +124,8 @@ int metadata_noise_launch(const char* who, int64_t rows, int64_t F, int n_cols, 
   if (rc != TAD_OK) return rc;
   if (rows == 0) return TAD_OK;
   if (n_cols > 0) {
-    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * n_cols, TV_STREAM);
-    TAD_CHECK(e == hipSuccess, "%s: hipMemsetAsync failed: %s", who, hipGetErrorString(e));
+    hipError_t e = tad_zero_async(stats, sizeof(double) * 2 * n_cols, TV_STREAM);
+    TAD_CHECK(e == hipSuccess, "%s: zeroing the statistics failed: %s", who, hipGetErrorString(e));
     hipLaunchKernelGGL(colstats_kernel<0>, dim3(tv_grid(rows)), dim3(TV_BLOCK), 0, TV_STREAM, rows, n_cols, cs, cond, ld, stats);
     hipLaunchKernelGGL(colstats_kernel<1>, dim3(tv_grid(rows)), dim3(TV_BLOCK), 0, TV_STREAM, rows, n_cols, cs, cond, ld, stats);
   }
