@@ -24,6 +24,8 @@ SAMPLE_FUSED_TAIL = os.environ.get("TAD_SAMPLE_FUSED_TAIL", "1") != "0"
 SAMPLE_FOLD = os.environ.get("TAD_SAMPLE_FOLD", "1") != "0"
 # the denoiser keeps its product-only tensors as bf16 up to this 4 H (products with K > 1024 take the square-tiled kernel)
 MM16_MAX_4H = int(os.environ.get("TAD_MM16_MAX_4H", "4096"))
+# the VAE decoder's products on bf16-stored operands (bf16 mode)
+VAE_DEC16 = os.environ.get("TAD_VAE_DEC16", "1") != "0"
 # input-side products of a recurrent layer whose weight has at least this many elements take the square-tiled kernel
 XPROJ_TILED_MIN = int(os.environ.get("TAD_XPROJ_TILED_MIN", str(1 << 21)))
 # TAD_SAMPLE_GRAPH=1: replay the reverse loop as one captured HIP graph per batch shape instead of enqueueing it kernel
@@ -244,6 +246,7 @@ class W16Images:
         self.fp = fp
         self.items = []
         self.sums = []
+        self.copies = []
         self._ver = -1
 
     @staticmethod
@@ -277,11 +280,20 @@ class W16Images:
         self.sums.append((biases[0], biases[1], bsum))
         return dict(fwd=img, bias=bsum, widths=widths)
 
+    def add_padded_bias(self, b, n_pad):
+        """float32 copy of the bias vector b, zero-padded to n_pad entries (a product whose result is padded to a multiple of
+        8 columns reads that many), refreshed with the images."""
+        out = torch.zeros(n_pad, dtype=torch.float32, device=b.device)
+        self.copies.append((b, out))
+        return out
+
     def pack(self):
         if self._ver != self.fp.version:
             ops.pack_w16(self.items)
             for a, b, out in self.sums:
                 ops.add_vec(a.reshape(-1), b.reshape(-1), out)
+            for src, dst in self.copies:
+                ops.copy_2d(src.reshape(1, -1), dst[:src.numel()].view(1, -1))
             self._ver = self.fp.version
 
 
@@ -1383,6 +1395,14 @@ class VAEEngine:
         if MM16 and self.prec == BF16 and self.H % 8 == 0 and all(self.enc.mm16):
             self.im = dict(fc_mu=self.imgs.add(self.fp.p("fc_mu.weight"), fwd=False, tr=True),
                            fc_logvar=self.imgs.add(self.fp.p("fc_logvar.weight"), fwd=False, tr=True))
+            if VAE_DEC16:
+                # the decoder's three products (reference VAE.py:200-219) on bf16-stored operands as well: z padded to 8 columns,
+                # the fused head outputs to a multiple of 8 (the spare columns meet zero weights and are never read)
+                self.NHp = -(-self.NH // 8) * 8
+                self.im["d0"] = self.imgs.add(self.fp.p("decoder_mlp.0.weight"), fwd=True, tr=True)
+                self.im["d2"] = self.imgs.add(self.fp.p("decoder_mlp.2.weight"), fwd=True, tr=True)
+                self.im["hd"] = self.imgs.add(self.fp.pgroup(self.head_w0, self.NH, self.H), fwd=True, tr=True)
+                self.im["hd_bias"] = self.imgs.add_padded_bias(self.fp.pgroup(self.head_b0, 1, self.NH).view(-1), self.NHp)
         self.ws = Workspace(device)
 
     def encoder(self, inp, eps, train=False, tag="enc", kld_sum=None):
@@ -1404,6 +1424,13 @@ class VAEEngine:
         self._enc_saved = (hh, eps2, B, T)
         return z.view(B, T, Lt), mu.view(B, T, Lt), lv.view(B, T, Lt)
 
+    def _dheads(self, ws, BT):
+        """Gradient of the loss with respect to the head outputs, with the row stride of the head outputs (the loss kernel
+        walks both with one stride); the pad columns of the bf16-stored form stay zero."""
+        if "d0" in self.im:
+            return ws.get("dheads_p", (BT, self.NHp), zero="new")[:, :self.NH]
+        return ws.get("dheads", (BT, self.NH))
+
     def decoder(self, z, mask, cond, target=None, scales=None, loss_parts=None, train=False):
         """z [B,T,L], mask [B,T,F] float, cond [B,T,F] or None -> fused head outputs [B*T, NH]
         (bins | cats | nums, reference-visible values).  With ``target``/``scales``/``loss_parts``
@@ -1414,17 +1441,39 @@ class VAEEngine:
         BT = B * T
         z2 = z.reshape(BT, Lt)
         m2 = mask.reshape(BT, self.F)
-        d1 = ws.get("d1", (BT, H))
-        ops.linear_fwd(prec, z2, fp.p("decoder_mlp.0.weight"), fp.p("decoder_mlp.0.bias"), d1, act=ACT_RELU)
-        lat = ws.get("lat", (BT, H))
-        ops.linear_fwd(prec, d1, fp.p("decoder_mlp.2.weight"), fp.p("decoder_mlp.2.bias"), lat)
         ce = None
-        if cond is not None:
-            ce = self.emb_dec.forward(cond.reshape(BT, self.F), ws, "embdec")
-            ops.linear_fwd(prec, ce, fp.p("Emb_hidden_decoder.weight"), fp.p("Emb_hidden_decoder.bias"), lat, accumulate=True)
-        heads = ws.get("heads", (BT, self.NH))
-        ops.linear_fwd(prec, lat, fp.pgroup(self.head_w0, self.NH, H), fp.pgroup(self.head_b0, 1, self.NH), heads)
-        dheads = ws.get("dheads", (BT, self.NH)) if train else None
+        if "d0" in self.im:
+            # d1, lat and their gradients are read by matrix products only: bf16 where they are produced
+            b16 = torch.bfloat16
+            im = self.im
+            self.imgs.pack()
+            Lp = -(-Lt // 8) * 8
+            z16 = ws.get("z16", (BT, Lp), dtype=b16, zero="new")        # the pad columns stay zero
+            ops.cvt_bf16(z2, z16[:, :Lt])
+            d1 = ws.get("d1_16", (BT, H), dtype=b16)
+            ops.mm16_nt(z16, im["d0"]["fwd"], fp.p("decoder_mlp.0.bias"), d1, act=ACT_RELU)
+            lat = ws.get("lat16", (BT, H), dtype=b16)
+            if cond is not None:
+                ce = self.emb_dec.forward(cond.reshape(BT, self.F), ws, "embdec")
+                latc = ws.get("latc", (BT, H))
+                ops.linear_fwd(prec, ce, fp.p("Emb_hidden_decoder.weight"), fp.p("Emb_hidden_decoder.bias"), latc)
+                ops.mm16_nt(d1, im["d2"]["fwd"], fp.p("decoder_mlp.2.bias"), lat, residual=latc)
+            else:
+                ops.mm16_nt(d1, im["d2"]["fwd"], fp.p("decoder_mlp.2.bias"), lat)
+            heads_p = ws.get("heads_p", (BT, self.NHp))
+            ops.mm16_nt(lat, im["hd"]["fwd"], im["hd_bias"], heads_p)
+            heads = heads_p[:, :self.NH]
+        else:
+            d1 = ws.get("d1", (BT, H))
+            ops.linear_fwd(prec, z2, fp.p("decoder_mlp.0.weight"), fp.p("decoder_mlp.0.bias"), d1, act=ACT_RELU)
+            lat = ws.get("lat", (BT, H))
+            ops.linear_fwd(prec, d1, fp.p("decoder_mlp.2.weight"), fp.p("decoder_mlp.2.bias"), lat)
+            if cond is not None:
+                ce = self.emb_dec.forward(cond.reshape(BT, self.F), ws, "embdec")
+                ops.linear_fwd(prec, ce, fp.p("Emb_hidden_decoder.weight"), fp.p("Emb_hidden_decoder.bias"), lat, accumulate=True)
+            heads = ws.get("heads", (BT, self.NH))
+            ops.linear_fwd(prec, lat, fp.pgroup(self.head_w0, self.NH, H), fp.pgroup(self.head_b0, 1, self.NH), heads)
+        dheads = self._dheads(ws, BT) if train else None
         t2 = target.reshape(BT, self.F) if target is not None else m2
         s = scales if scales is not None else (0.0, 0.0, 0.0)
         ops.vae_heads_loss(heads, m2, t2, self.nb, self.nc, self.nn, self.cards, s[0], s[1], s[2], dheads, loss_parts)
@@ -1470,24 +1519,55 @@ class VAEEngine:
         z2, ce, B, T = self._dec_saved
         hh, eps2, _, _ = self._enc_saved
         BT = B * T
-        dheads = ws.get("dheads", (BT, self.NH))
-        lat = ws.get("lat", (BT, H))
-        d1 = ws.get("d1", (BT, H))
+        dheads = self._dheads(ws, BT)
         mu = ws.get("mu", (BT, Lt))
         lv = ws.get("lv", (BT, Lt))
-        dlat = ws.get("dlat", (BT, H))
-        _lin_bwd(fp, prec, dheads, lat, fp.pgroup(self.head_w0, self.NH, H), fp.ggroup(self.head_w0, self.NH, H),
-                 fp.ggroup(self.head_b0, 1, self.NH), dx=dlat)
-        if ce is not None:
-            dce = ws.get("dce", (BT, self.F))
-            _lin_bwd(fp, prec, dlat, ce, fp.p("Emb_hidden_decoder.weight"), fp.g("Emb_hidden_decoder.weight"),
-                     fp.g("Emb_hidden_decoder.bias"), dx=dce)
-            self.emb_dec.backward(dce, ws, "embdec")
-        dd1 = ws.get("dd1", (BT, H))
-        _lin_bwd(fp, prec, dlat, d1, fp.p("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.bias"),
-                 dx=dd1, relu_of=d1)
         dz = ws.get("dz", (BT, Lt))
-        _lin_bwd(fp, prec, dd1, z2, fp.p("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.bias"), dx=dz)
+        if "d0" in self.im:
+            b16 = torch.bfloat16
+            im = self.im
+            Lp = -(-Lt // 8) * 8
+            lat = ws.get("lat16", (BT, H), dtype=b16)
+            d1 = ws.get("d1_16", (BT, H), dtype=b16)
+            z16 = ws.get("z16", (BT, Lp), dtype=b16)
+            dh16 = ws.get("dheads16", (BT, self.NHp), dtype=b16)
+            ops.cvt_bf16(ws.get("dheads_p", (BT, self.NHp)), dh16)
+            fp.queue_tn(dh16, dict(b=lat, c=fp.ggroup(self.head_w0, self.NH, H), db=fp.ggroup(self.head_b0, 1, self.NH).view(-1),
+                                   a0=0, na=self.NH))
+            dlat = ws.get("dlat16", (BT, H), dtype=b16)
+            if ce is not None:
+                # the conditioning branch reads d(lat) through the fp32-operand products: an fp32 copy for it
+                dlat32 = ws.get("dlat", (BT, H))
+                ops.mm16_nt(dh16, im["hd"]["tr"], None, dlat32)
+                ops.cvt_bf16(dlat32, dlat)
+                dce = ws.get("dce", (BT, self.F))
+                _lin_bwd(fp, prec, dlat32, ce, fp.p("Emb_hidden_decoder.weight"), fp.g("Emb_hidden_decoder.weight"),
+                         fp.g("Emb_hidden_decoder.bias"), dx=dce)
+                self.emb_dec.backward(dce, ws, "embdec")
+            else:
+                ops.mm16_nt(dh16, im["hd"]["tr"], None, dlat)
+            fp.queue_tn(dlat, dict(b=d1, c=fp.g("decoder_mlp.2.weight"), db=fp.g("decoder_mlp.2.bias")))
+            dd1 = ws.get("dd1_16", (BT, H), dtype=b16)
+            ops.mm16_nt(dlat, im["d2"]["tr"], None, dd1, relu_of=d1)
+            fp.queue_tn(dd1, dict(b=z16, c=fp.g("decoder_mlp.0.weight"), db=fp.g("decoder_mlp.0.bias")))
+            dzp = ws.get("dz_p", (BT, Lp))
+            ops.mm16_nt(dd1, im["d0"]["tr"], None, dzp)
+            ops.copy_2d(dzp[:, :Lt], dz)
+        else:
+            lat = ws.get("lat", (BT, H))
+            d1 = ws.get("d1", (BT, H))
+            dlat = ws.get("dlat", (BT, H))
+            _lin_bwd(fp, prec, dheads, lat, fp.pgroup(self.head_w0, self.NH, H), fp.ggroup(self.head_w0, self.NH, H),
+                     fp.ggroup(self.head_b0, 1, self.NH), dx=dlat)
+            if ce is not None:
+                dce = ws.get("dce", (BT, self.F))
+                _lin_bwd(fp, prec, dlat, ce, fp.p("Emb_hidden_decoder.weight"), fp.g("Emb_hidden_decoder.weight"),
+                         fp.g("Emb_hidden_decoder.bias"), dx=dce)
+                self.emb_dec.backward(dce, ws, "embdec")
+            dd1 = ws.get("dd1", (BT, H))
+            _lin_bwd(fp, prec, dlat, d1, fp.p("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.weight"), fp.g("decoder_mlp.2.bias"),
+                     dx=dd1, relu_of=d1)
+            _lin_bwd(fp, prec, dd1, z2, fp.p("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.weight"), fp.g("decoder_mlp.0.bias"), dx=dz)
         dmu = ws.get("dmu", (BT, Lt))
         dlv = ws.get("dlv", (BT, Lt))
         ops.vae_reparam_bwd(dz, mu, lv, eps2, beta / (global_rows * Lt), dmu, dlv)
