@@ -2,7 +2,8 @@
 HIP graph, idle and beside memory-bound work, every result compared bit for bit with the first.  Prints where a launch that
 differs first differs (direction, tile of 128 rows, quarter, time step, owning workgroups) and the workspace's status.
 
-  python scripts/cl_stress.py [launches per mode, default 1500] [cell 0 = LSTM | 1 = GRU | 2 = both]
+  python scripts/cl_stress.py [launches per mode, default 1500] [cell 0 = LSTM | 1 = GRU | 2 = both] [B, default 700] [T, default 7]
+(B = 4200: 66 (tile, direction) items on 32 groups, so that groups walk several items and reuse their exchange buffers)
 """
 import sys
 import time
@@ -101,7 +102,7 @@ def memset_node_check():
 
 def main():
     memset_node_check()
-    B, T, nd = 700, 7, 2
+    B, T, nd = (int(sys.argv[3]) if len(sys.argv) > 3 else 700), (int(sys.argv[4]) if len(sys.argv) > 4 else 7), 2
     for cell in CELLS:
         run = problem(cell, B, T, nd, 77 + cell)
         nws = ops.rnn_workspace_bytes(cell, 1, 1, B, T, H, nd)
@@ -142,7 +143,7 @@ def main():
                 eq = [torch.equal(a, b_) for a, b_ in zip(got, ref)]
                 ctr = ws[:16384].view(torch.int32).view(-1, 32)[:, 0]
                 if rep < 2 or (not all(eq) and nbad < 4):
-                    print(f"  {mode} launch {rep}: counters after the launch: {sorted(set(ctr[:48].tolist()))}", flush=True)
+                    print(f"  {mode} launch {rep}: counters after the launch: {sorted(set(ctr[:4 * min(32, 2 * -(-B // 128))].tolist()))}", flush=True)
                 if not all(eq):
                     nbad += 1
                     if nbad <= 4:
