@@ -302,7 +302,8 @@ int tad_sampler_update(int64_t n, float* x, const float* pred, const float* z, f
  * tad_sampler_update on x [rows, K] with z [rows, K] (DIFF.py:348-351) -> input_proj of the UPDATED x for the
  * next step (DIFF.py:198; w_in [H, K], b_in [H]) into xh [rows, H] (row stride ldxh).  prec = TAD_BF16 rounds
  * the operands of the two projections to bf16 like the matrix products they replace.  D <= 1024, K <= 8,
- * H*(K+1) <= 12288; other shapes take tad_layernorm_fwd + tad_linear_fwd + tad_sampler_update. */
+ * H <= 1024 and 10 H + 3 + 512 n <= 16384 (the launch's LDS), n = 2, 8 or 16: the least of them that is at least
+ * max(D, H) / 64; other shapes take tad_layernorm_fwd + tad_linear_fwd + tad_sampler_update. */
 int tad_sampler_tail(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
                      const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
                      float c1, float c2, float c3, int last, const float* w_in, const float* b_in, float* xh,
@@ -321,6 +322,15 @@ int tad_sampler_tail_proj_b16(int prec, int64_t rows, int D, int K, int H, const
                               float c1, float c2, float c3, int last, const float* w_fold, const float* b_fold,
                               const float* vrow, const float* pinv, int64_t ld_pinv, void* pa16, int64_t ldpa,
                               tad_stream_t stream);
+/* tad_sampler_tail_proj_b16 drawing the step's noise itself instead of reading z: lane k of a row's wave evaluates the
+ * value tad_sampler_noise(seed, counter, ...) gives element k of global row row0 + r (bit for bit), while the row's loads
+ * are in flight -- the noise tensor of a reverse step (DIFF.py:346 `torch.randn_like(x)`) is neither written nor read and
+ * its launch disappears. */
+int tad_sampler_tail_proj_cn_b16(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
+                                 const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, uint64_t seed,
+                                 uint64_t counter, int64_t row0, float c1, float c2, float c3, int last, const float* w_fold,
+                                 const float* b_fold, const float* vrow, const float* pinv, int64_t ld_pinv, void* pa16,
+                                 int64_t ldpa, tad_stream_t stream);
 /* The same launch with the next step's input projection written as bf16 (it feeds `proj`'s product only). */
 int tad_sampler_tail_b16(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
                      const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,

@@ -1,10 +1,10 @@
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, '.')
 import bench
 from timeautodiff_amd import DIFF, ops
 dev = torch.device('cuda:0')
 cx = bench.Ctx(dev, 1, 0) if hasattr(bench, 'Ctx') else None
-for name in ('stock_T24_H200', 'energy_T24_H200'):
+for name in ('energy_T24_H200',):
     wl = bench.WORKLOADS[name]
     schema = wl['schema']
     F_ = schema['n_bins'] + schema['n_cats'] + schema['n_nums']
@@ -14,7 +14,7 @@ for name in ('stock_T24_H200', 'energy_T24_H200'):
     model.set_compute_dtype('bf16')
     Bs = 1024
     tg = torch.linspace(0, 1, wl['T'], device=dev).view(1, -1, 1).repeat(Bs, 1, 1)
-    run = lambda: DIFF.sample(tg, Bs, wl['T'], bench.K, 100, model, time_info[:Bs], cond[:Bs], None, noise_source='device')
+    run = lambda: DIFF.sample(tg, Bs, wl['T'], bench.K, 100, model, time_info[:Bs], cond[:Bs], None, noise_source='device', streams=int(os.environ.get('STREAMS', '2')))
     for _ in range(2): run()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3): run()

@@ -1129,7 +1129,7 @@ def test_sampler_tail_equals_the_four_launches(ops, dev, prec, shape):
     assert torch.all(xhb._base[:, H:] == 7.0)
 
 
-@pytest.mark.parametrize("rows,Dm,K,H,last", [(300, 400, 6, 200, False), (70, 1024, 6, 512, True), (33, 256, 8, 128, False)])
+@pytest.mark.parametrize("rows,Dm,K,H,last", [(300, 400, 6, 200, False), (70, 1024, 6, 512, True), (33, 256, 8, 128, False), (45, 128, 5, 64, True)])
 def test_sampler_tail_with_folded_proj_share(ops, dev, rows, Dm, K, H, last):
     """tad_sampler_tail_proj_b16 -- the tail of a reverse step that also leaves relu(x_new (W_1 W_in)^T + W_1 b_in + V[s] +
     pinv), the LSTM's operand of the NEXT step -- against the two launches it replaces (tad_sampler_tail_b16, then the
@@ -1160,6 +1160,17 @@ def test_sampler_tail_with_folded_proj_share(ops, dev, rows, Dm, K, H, last):
     assert float((got - ref).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
     assert float((got - ref).abs().mean()) <= 2.0 ** -9 * float(ref.abs().mean() + 1e-6) * 4
     assert torch.all(pa16._base[:, H:] == 7.0) and torch.all(got >= 0)
+    # the same launch drawing the step's noise itself: bit for bit what it gives on the tensor tad_sampler_noise writes,
+    # for rows that start anywhere in the global tensor (a chunk, a rank), odd K included
+    seed, step, row0 = 0x1234_5678_9ABC_DEF0, 37, 1000 * rows + 3
+    zc = torch.empty(rows, K, device=dev)
+    ops.sampler_noise(seed, step, row0, rows, K, zc)
+    xc, xd = x0.clone(), x0.clone()
+    pc = torch.empty(rows, H, dtype=torch.bfloat16, device=dev)
+    pd = torch.empty_like(pc)
+    ops.sampler_tail_proj(1, h, gamma, beta, fc_w, fc_b, xc, zc, c1, c2, c3, last, wc, bc, vrow, pinv, pc)
+    ops.sampler_tail_proj_cn(1, h, gamma, beta, fc_w, fc_b, xd, seed, step, row0, c1, c2, c3, last, wc, bc, vrow, pinv, pd)
+    assert torch.equal(xc, xd) and torch.equal(pc, pd)
 
 
 # ---------------------------------------------------------------------------- TV-MCG metadata corruption

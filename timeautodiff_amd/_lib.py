@@ -79,6 +79,8 @@ PROTOTYPES = {
     "tad_sampler_tail_b16": (_i, [_i, _i64, _i, _i, _i, _p, _i64, _p, _p, _f, _p, _p, _p, _p, _f, _f, _f, _i, _p, _p, _p, _i64, _p]),
     "tad_sampler_tail_proj_b16": (_i, [_i, _i64, _i, _i, _i, _p, _i64, _p, _p, _f, _p, _p, _p, _p, _f, _f, _f, _i, _p, _p, _p, _p, _i64, _p,
                                        _i64, _p]),
+    "tad_sampler_tail_proj_cn_b16": (_i, [_i, _i64, _i, _i, _i, _p, _i64, _p, _p, _f, _p, _p, _p, C.c_uint64, C.c_uint64, _i64, _f, _f, _f, _i,
+                                          _p, _p, _p, _p, _i64, _p, _i64, _p]),
     "tad_mse_loss": (_i, [_i64, _p, _p, _f, _p, _p, _p]),
     "tad_grad_norm_sq": (_i, [_i64, _p, _p, _p]),
     "tad_ln_fc_fwd": (_i, [_i, _i64, _i, _i, _p, _i64, _p, _p, _f, _p, _p, _p, _i64, _p, _p, _p]),

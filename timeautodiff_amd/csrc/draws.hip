@@ -6,26 +6,11 @@
 #include <math.h>
 
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
-// ---------------------------------------------------------------------------------------------- Philox4x32-10
-struct u4 { uint32_t x, y, z, w; };
-
-__device__ __forceinline__ u4 philox4x32_10(u4 c, uint32_t k0, uint32_t k1) {
-  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-    const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
-    c = u4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
-    k0 += W0; k1 += W1;
-  }
-  return c;
-}
-
-// the streams of one draw: counter word 2 of the Philox input
-enum { ST_PERM = 0, ST_T = 1, ST_I = 2, ST_NOISE = 3, ST_SAMPLER = 4 };
+using namespace tad_rng;
 
 struct DrawArgs {
   uint32_t k0, k1, counter;     // key = seed, counter word 3 = the iteration
@@ -38,8 +23,6 @@ struct DrawArgs {
 __device__ __forceinline__ u4 draw(const DrawArgs& a, int stream, uint64_t e) {
   return philox4x32_10(u4{(uint32_t)e, (uint32_t)(e >> 32), (uint32_t)stream, a.counter}, a.k0, a.k1);
 }
-__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }            // [0, 1)
-__device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }   // (0, 1]
 
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
   h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
@@ -111,13 +94,10 @@ __global__ void sampler_noise_kernel(uint32_t k0, uint32_t k1, uint32_t counter,
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / P;
     const int p = (int)(e - r * P);
-    const uint64_t ge = (uint64_t)((row0 + r) * P + p);
-    const u4 d = philox4x32_10(u4{(uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)ST_SAMPLER, counter}, k0, k1);
-    const float rad = sqrtf(-2.0f * logf(u01_open(d.x)));
-    float s, c;
-    sincosf(6.283185307179586f * u01(d.y), &s, &c);
-    out[r * K + 2 * p] = rad * c;
-    if (2 * p + 1 < K) out[r * K + 2 * p + 1] = rad * s;
+    float even, odd;
+    sampler_noise_pair(k0, k1, counter, row0 + r, P, p, even, odd);
+    out[r * K + 2 * p] = even;
+    if (2 * p + 1 < K) out[r * K + 2 * p + 1] = odd;
   }
 }
 

@@ -3,8 +3,10 @@
 // fastest dimension, wave-level reductions (64 lanes) followed by one atomic per wave
 // or workgroup for the scalar / per-column results.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -400,98 +402,200 @@ __global__ void layernorm_fwd_kernel(int64_t rows, int D, const float* __restric
   }
 }
 
+// Where the noise of a reverse step comes from when the tail draws it itself (tad_sampler_noise's values, bit for bit).
+struct TailNoise {
+  uint32_t k0, k1, counter;
+  int on;
+  int64_t row0;          // global row of the launch's first row
+};
+
 // Tail of one reverse-diffusion step, one wave per row (= one (sequence, time) pair): LayerNorm of the recurrent
 // output row (kept in registers, as layernorm_fwd_kernel), the K-wide output projection, the sampler update of
 // the row's K latent values, and the input projection of the UPDATED values for the next step.  round16: the
 // operands of the two projections are rounded to bf16 where a bf16 matrix product would round them.
-template <int NC, int KMAX>
-__global__ void sampler_tail_kernel(int64_t rows, int D, int K, int H, int round16, const float* __restrict__ h, int64_t ldh,
+// A row costs its instructions, not its bytes (the first form ran 2400 per row, most of them lane masks and scalar
+// guards of the unrolled loops): every load of a row is issued at the top of its iteration through clamped addresses
+// (no branch around a load), the two weight matrices sit in LDS padded to 8 values per column, read 16 bytes at a time,
+// loops over the K outputs have no guards where K is the template's KT (KT = 0: any K <= 8, guarded).
+template <int NC, int KT>
+__global__ __launch_bounds__(EW_BLOCK) void sampler_tail_kernel(int64_t rows, int D, int K, int H, int round16, const float* __restrict__ h, int64_t ldh,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                     const float* __restrict__ fcw, const float* __restrict__ fcb, float* __restrict__ x,
-                                    const float* __restrict__ z, float c1, float c2, float c3, int last,
+                                    const float* __restrict__ z, TailNoise nz, float c1, float c2, float c3, int last,
                                     const float* __restrict__ w_in, const float* __restrict__ b_in,
                                     float* __restrict__ xh, int64_t ldxh, bf16_t* __restrict__ xh16,
                                     const float* __restrict__ vrow, const float* __restrict__ pinv, int64_t ldp) {
-  extern __shared__ float tail_lds[];          // w_in [H, K] (rounded), then b_in [H]
+  constexpr int KMAX = 8;
+  constexpr int KN = KT ? KT : KMAX;           // trip count of the loops over the outputs
+  extern __shared__ __attribute__((aligned(16))) float tail_lds[];
+  // LDS: w_in [H][8] (rounded, zeros beyond K), b_in [H], vrow [H], fc's weight [64 NC][8] (rounded, zeros beyond K and D).
   // pinv != NULL: w_in / b_in are the input projection folded into the x share of `proj` (prepared by the caller from
   // rounded factors: not rounded again) and the row leaves as relu(. + vrow + pinv[r]), the operand of the LSTM's input side
-  for (int e = threadIdx.x; e < H * K; e += blockDim.x) tail_lds[e] = (round16 && !pinv) ? (float)(bf16_t)w_in[e] : w_in[e];
-  for (int e = threadIdx.x; e < H; e += blockDim.x) tail_lds[H * K + e] = b_in[e];
+  float* const win = tail_lds;
+  float* const bin = tail_lds + (size_t)H * KMAX;
+  float* const vr = bin + H;
+  float* const fw = vr + H + ((4 - ((2 * H) & 3)) & 3);      // 16-byte aligned
+  // (the fills keep eight loads per thread in flight through clamped addresses: a branch around each load made the
+  // prologue of a workgroup a chain of sixteen round trips to L2, half of the launch's time)
+  auto fill = [&](float* dst, int n, auto value) {
+    for (int e0 = threadIdx.x; e0 < n; e0 += 8 * EW_BLOCK) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + j * EW_BLOCK;
+        v[j] = value(e < n ? e : n - 1);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + j * EW_BLOCK;
+        if (e < n) dst[e] = v[j];
+      }
+    }
+  };
+  const bool round_in = round16 && !pinv;
+  fill(win, H * KMAX, [&](int e) {
+    const int u = e >> 3, k = e & 7;
+    const float w = w_in[u * K + (k < K ? k : K - 1)];
+    const float wr = round_in ? (float)(bf16_t)w : w;
+    return k < K ? wr : 0.f;
+  });
+  fill(bin, H, [&](int e) { return b_in[e]; });
+  if (pinv) fill(vr, H, [&](int e) { return vrow[e]; });
+  fill(fw, 64 * NC * KMAX, [&](int e) {
+    const int c = e >> 3, k = e & 7;
+    const float w = fcw[(int64_t)(k < K ? k : K - 1) * D + (c < D ? c : D - 1)];
+    const float wr = round16 ? (float)(bf16_t)w : w;
+    return (c < D && k < K) ? wr : 0.f;
+  });
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  float gm[NC], bt[NC], wk[KMAX][NC];
+  const int nD = (D + 63) >> 6, nH = (H + 63) >> 6;        // 64-column blocks of a row that exist
+  float gm[NC], bt[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
-    const int c = lane + 64 * i;
-    gm[i] = c < D ? gamma[c] : 0.f;
-    bt[i] = c < D ? beta[c] : 0.f;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const float w = (c < D && k < K) ? fcw[(int64_t)k * D + c] : 0.f;
-      wk[k][i] = round16 ? (float)(bf16_t)w : w;
-    }
+    const int c = lane + 64 * i, cc = c < D ? c : D - 1;
+    const float g_ = gamma[cc], b_ = beta[cc];
+    gm[i] = c < D ? g_ : 0.f;
+    bt[i] = c < D ? b_ : 0.f;
   }
-  for (int64_t r = wave; r < rows; r += nwaves) {
-    const float* hr = h + r * ldh;
-    float xv[NC];
-    float s = 0.f;
+  const int kl = lane < K ? lane : K - 1;
+  const float fcb_l = fcb[kl];
+  // The loads of row r + nwaves are issued before row r's stores: the wait for loaded values releases in issue order, so
+  // loads issued behind the stores would wait for the stores' acknowledgements too (a row then took its store latency, its
+  // load latency and its arithmetic one after the other: 5 us).
+  float xq[NC], pq[NC], xo_q, z_q;
+  auto fetch = [&](int64_t rr) {
+    if (rr >= rows) rr = rows - 1;               // (uniform; the values are not used)
+    const float* hr = h + rr * ldh;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
-      xv[i] = c < D ? hr[c] : 0.f;
-      if (c < D) s += xv[i];
+      xq[i] = i < nD ? hr[c < D ? c : D - 1] : 0.f;
+    }
+    xo_q = x[rr * K + kl];
+    z_q = nz.on ? 0.f : z[rr * K + kl];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int u = lane + 64 * i;
+      pq[i] = (pinv && i < nH) ? pinv[rr * ldp + (u < H ? u : H - 1)] : 0.f;
+    }
+  };
+  if (wave < rows) fetch(wave);
+  // In-launch noise: a draw costs some 350 instructions and a row has K values, so the wave draws for its next 64 / K rows
+  // at once (lane = (row of the batch, k)) and each row picks its K values up from those lanes.
+  const int rpb = 64 / K;                        // rows per batch of draws
+  const int bl_row = lane / K, bl_k = lane - bl_row * K;
+  float zbatch = 0.f;
+  int jj = 0;                                    // the row's place in its batch
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    float xv[NC], pv[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { xv[i] = xq[i]; pv[i] = pq[i]; }
+    const float x_old = xo_q;
+    float zv = z_q;
+    fetch(r + nwaves);
+    if (nz.on) {            // (arithmetic only: runs while the loads are in flight)
+      if (jj == 0) {
+        float even, odd;
+        tad_rng::sampler_noise_pair(nz.k0, nz.k1, nz.counter, nz.row0 + r + (int64_t)bl_row * nwaves, (K + 1) >> 1, bl_k >> 1, even, odd);
+        zbatch = (bl_k & 1) ? odd : even;
+      }
+      zv = __shfl(zbatch, jj * K + kl, 64);
+      jj = jj + 1 == rpb ? 0 : jj + 1;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      if (lane + 64 * i >= D) xv[i] = 0.f;
+      s += xv[i];
     }
     const float mean = wave_sum(s) / (float)D;
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const float dlt = xv[i] - mean;
-      if (lane + 64 * i < D) v += dlt * dlt;
+      v += lane + 64 * i < D ? dlt * dlt : 0.f;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
-    float acc[KMAX];
+    float acc[KN];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+    for (int k = 0; k < KN; ++k) acc[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-      float y = (xv[i] - mean) * rstd * gm[i] + bt[i];
-      if (round16) y = (float)(bf16_t)y;
-      if (lane + 64 * i >= D) y = 0.f;
+      if (i < nD) {
+        float y = (xv[i] - mean) * rstd * gm[i] + bt[i];
+        if (round16) y = (float)(bf16_t)y;
+        if (lane + 64 * i >= D) y = 0.f;
+        const float4 w0 = *reinterpret_cast<const float4*>(fw + (size_t)(lane + 64 * i) * KMAX);
+        const float4 w1 = *reinterpret_cast<const float4*>(fw + (size_t)(lane + 64 * i) * KMAX + 4);
+        const float w8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) acc[k] += y * wk[k][i];
-    }
-    float mine = 0.f;                            // lane k < K ends up with the updated x[r, k]
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      if (k < K) {
-        const float p = wave_sum(acc[k]) + fcb[k];
-        if (lane == k) {
-          const int64_t e = r * K + k;
-          // same operation order as sampler_update_kernel
-          float nv = __fadd_rn(__fmul_rn(c1, __fsub_rn(x[e], __fmul_rn(c2, p))), __fmul_rn(c3, z[e]));
-          if (last) nv = __fmul_rn(c1, __fsub_rn(nv, __fmul_rn(c2, p)));
-          x[e] = nv;
-          mine = nv;
-        }
+        for (int k = 0; k < KN; ++k) acc[k] += y * w8[k];
       }
     }
-    float xn[KMAX];
+    float pk = 0.f;                              // lane k < K: the row's prediction k (before the bias)
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const float t = __shfl(mine, k, 64);
+    for (int k = 0; k < KN; ++k) {
+      if (KT || k < K) {
+        const float t = wave_sum(acc[k]);
+        if (lane == k) pk = t;
+      }
+    }
+    float mine;                                  // lane k < K: the updated x[r, k]
+    {
+      const float p = pk + fcb_l;
+      // same operation order as sampler_update_kernel
+      float nv = __fadd_rn(__fmul_rn(c1, __fsub_rn(x_old, __fmul_rn(c2, p))), __fmul_rn(c3, zv));
+      if (last) nv = __fmul_rn(c1, __fsub_rn(nv, __fmul_rn(c2, p)));
+      if (lane < K) x[r * K + lane] = nv;
+      mine = nv;
+    }
+    float xn[KN];
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), k));
       xn[k] = round16 ? (float)(bf16_t)t : t;
     }
-    for (int u = lane; u < H; u += 64) {
-      float a = 0.f;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
-        if (k < K) a += xn[k] * tail_lds[u * K + k];
-      float o = a + tail_lds[H * K + u];
-      if (pinv) o = fmaxf((o + vrow[u]) + pinv[r * ldp + u], 0.f);
-      if (xh16) xh16[r * ldxh + u] = (bf16_t)o;            // the next step's `proj` reads it as a bf16 operand
-      else xh[r * ldxh + u] = o;
+    for (int i = 0; i < NC; ++i) {
+      if (i < nH) {
+        const int u = lane + 64 * i, uc = u < H ? u : H - 1;
+        const float4 w0 = *reinterpret_cast<const float4*>(win + (size_t)uc * KMAX);
+        const float4 w1 = *reinterpret_cast<const float4*>(win + (size_t)uc * KMAX + 4);
+        const float w8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+          if (KT || k < K) a += xn[k] * w8[k];
+        float o = a + bin[uc];
+        if (pinv) o = fmaxf((o + vr[uc]) + pv[i], 0.f);
+        if (u < H) {
+          if (xh16) xh16[r * ldxh + u] = (bf16_t)o;            // the next step's `proj` reads it as a bf16 operand
+          else xh[r * ldxh + u] = o;
+        }
+      }
     }
   }
 }
@@ -969,20 +1073,27 @@ static int sampler_tail(int prec, int64_t rows, int D, int K, int H, const float
                         const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
                         float c1, float c2, float c3, int last, const float* w_in, const float* b_in, float* xh,
                         int64_t ldxh, bf16_t* xh16, tad_stream_t stream, const float* vrow = nullptr, const float* pinv = nullptr,
-                        int64_t ldp = 0) {
-  TAD_CHECK(rows >= 0 && D > 0 && D <= 1024 && K > 0 && K <= 8 && H > 0 && (int64_t)H * (K + 1) <= 12288,
-            "tad_sampler_tail: supported D <= 1024, K <= 8, H*(K+1) <= 12288 (got D=%d K=%d H=%d)", D, K, H);
-  TAD_CHECK(h && gamma && beta && fc_w && fc_b && x && z && w_in && b_in && (xh || xh16) && ldh >= D && ldxh >= H, "tad_sampler_tail: bad arguments");
+                        int64_t ldp = 0, TailNoise nz = TailNoise{}) {
+  TAD_CHECK(rows >= 0 && D > 0 && D <= 1024 && K > 0 && K <= 8 && H > 0 && H <= 1024, "tad_sampler_tail: supported D <= 1024, K <= 8, H <= 1024 (got D=%d K=%d H=%d)", D, K, H);
+  TAD_CHECK(h && gamma && beta && fc_w && fc_b && x && (z || nz.on) && w_in && b_in && (xh || xh16) && ldh >= D && ldxh >= H, "tad_sampler_tail: bad arguments");
   if (rows == 0) return TAD_OK;
   int64_t g = cdiv64(rows, EW_BLOCK / 64);
-  if (g > 1024) g = 1024;
-  const int nc = (int)cdiv64(D, 64);
-  const size_t lds = sizeof(float) * (size_t)H * (K + 1);
+  if (g > 512) g = 512;          // two workgroups per CU: the prologue (weights into LDS) is a third of a 25 k-row launch
+  int nc = (int)cdiv64(D > H ? D : H, 64);          // a lane's columns cover the recurrent output and the projection
+  nc = nc <= 2 ? 2 : nc <= 8 ? 8 : 16;
+  const size_t lds = sizeof(float) * ((size_t)H * 10 + 3 + (size_t)8 * 64 * nc);
+  TAD_CHECK(lds <= 65536, "tad_sampler_tail: 10 H + 512 ceil(max(D, H) / 64) exceeds the launch's LDS (D=%d K=%d H=%d)", D, K, H);
   const int r16 = prec == TAD_BF16 ? 1 : 0;
-#define TAIL(NC) hipLaunchKernelGGL((sampler_tail_kernel<NC, 8>), dim3((unsigned)g), dim3(EW_BLOCK), lds, EW_STREAM, rows, D, K, H, r16, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, c1, c2, c3, last, w_in, b_in, xh, ldxh, xh16, vrow, pinv, ldp)
-  if (nc <= 2) TAIL(2);
-  else if (nc <= 8) TAIL(8);
-  else TAIL(16);
+#define TAIL(NC, KT) hipLaunchKernelGGL((sampler_tail_kernel<NC, KT>), dim3((unsigned)g), dim3(EW_BLOCK), lds, EW_STREAM, rows, D, K, H, r16, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, nz, c1, c2, c3, last, w_in, b_in, xh, ldxh, xh16, vrow, pinv, ldp)
+  if (K == 6) {          // (the latent width of every reference notebook)
+    if (nc == 2) TAIL(2, 6);
+    else if (nc == 8) TAIL(8, 6);
+    else TAIL(16, 6);
+  } else {
+    if (nc == 2) TAIL(2, 0);
+    else if (nc == 8) TAIL(8, 0);
+    else TAIL(16, 0);
+  }
 #undef TAIL
   TAD_LAUNCH_CHECK();
   return TAD_OK;
@@ -1011,6 +1122,17 @@ extern "C" int tad_sampler_tail_proj_b16(int prec, int64_t rows, int D, int K, i
   TAD_CHECK(vrow && pinv && ld_pinv >= H && pa16, "tad_sampler_tail_proj_b16: bad arguments");
   return sampler_tail(prec, rows, D, K, H, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, c1, c2, c3, last, w_fold, b_fold, nullptr, ldpa,
                       reinterpret_cast<bf16_t*>(pa16), stream, vrow, pinv, ld_pinv);
+}
+
+extern "C" int tad_sampler_tail_proj_cn_b16(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
+                                            const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, uint64_t seed,
+                                            uint64_t counter, int64_t row0, float c1, float c2, float c3, int last, const float* w_fold,
+                                            const float* b_fold, const float* vrow, const float* pinv, int64_t ld_pinv, void* pa16,
+                                            int64_t ldpa, tad_stream_t stream) {
+  TAD_CHECK(vrow && pinv && ld_pinv >= H && pa16 && row0 >= 0 && counter < (1ull << 32), "tad_sampler_tail_proj_cn_b16: bad arguments");
+  TailNoise nz{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)counter, 1, row0};
+  return sampler_tail(prec, rows, D, K, H, h, ldh, gamma, beta, eps, fc_w, fc_b, x, nullptr, c1, c2, c3, last, w_fold, b_fold, nullptr, ldpa,
+                      reinterpret_cast<bf16_t*>(pa16), stream, vrow, pinv, ld_pinv, nz);
 }
 
 extern "C" int tad_mse_loss(int64_t n, const float* pred, const float* target, float grad_scale, float* dpred,

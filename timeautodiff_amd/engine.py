@@ -22,6 +22,8 @@ SAMPLE_STREAMS = int(os.environ.get("TAD_SAMPLE_STREAMS", "2"))
 SAMPLE_FUSED_TAIL = os.environ.get("TAD_SAMPLE_FUSED_TAIL", "1") != "0"
 # the x share of `proj` folded into the tail of the previous reverse step (bf16 mode): one product and one launch fewer per step
 SAMPLE_FOLD = os.environ.get("TAD_SAMPLE_FOLD", "1") != "0"
+# counter-based noise of a reverse step drawn inside the folded tail instead of by a launch of its own (experiments: 0)
+SAMPLE_TAIL_NOISE = os.environ.get("TAD_SAMPLE_TAIL_NOISE", "1") != "0"
 # the denoiser keeps its product-only tensors as bf16 up to this 4 H (products with K > 1024 take the square-tiled kernel)
 MM16_MAX_4H = int(os.environ.get("TAD_MM16_MAX_4H", "4096"))
 # the VAE decoder's products on bf16-stored operands (bf16 mode)
@@ -1303,6 +1305,14 @@ class DenoiserEngine:
         """Reverse step s for the sequences of one ``_sample_setup`` state, on the current stream."""
         fp, prec, H = self.fp, self.prec, self.H
         x2, xh, pa, ln, pred = st["x2"], st["xh"], st["pa"], st["ln"], st["pred"]
+        if st["fold"] and isinstance(st["z"], CounterNoise) and SAMPLE_TAIL_NOISE:
+            # the tail draws the step's noise itself (the same values, no tensor, no launch)
+            z = st["z"]
+            lout = self.lstm.forward(st["pa16"], st["B"], st["T"], st["ws"], "lstm", False)
+            ops.sampler_tail_proj_cn(prec, lout, fp.p("layer_norm.weight"), fp.p("layer_norm.bias"), fp.p("fc.weight"), fp.p("fc.bias"),
+                                     x2, z.seed, s, z.row0, coef[0][s], coef[1][s], coef[2][s], s == 0, st["wc"], st["bc"],
+                                     st["V"][max(s - 1, 0)], st["pinv"], st["pa16"])
+            return
         zs = self._step_noise(st, s)
         if st["fold"]:
             lout = self.lstm.forward(st["pa16"], st["B"], st["T"], st["ws"], "lstm", False)

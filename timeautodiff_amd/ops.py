@@ -787,7 +787,9 @@ def flip_categories(cond, cols, classes, rnd, base, p, out):
 
 
 def sampler_tail_supported(D, K, H):
-    return D <= 1024 and K <= 8 and H * (K + 1) <= 12288
+    nc = -(-max(D, H) // 64)
+    nc = 2 if nc <= 2 else 8 if nc <= 8 else 16
+    return D <= 1024 and K <= 8 and H <= 1024 and 10 * H + 3 + 512 * nc <= 16384
 
 
 def sampler_tail(prec, h, gamma, beta, fc_w, fc_b, x, z, c1, c2, c3, last, w_in, b_in, xh, eps=1e-5):
@@ -815,6 +817,21 @@ def sampler_tail_proj(prec, h, gamma, beta, fc_w, fc_b, x, z, c1, c2, c3, last, 
     _call("tad_sampler_tail_proj_b16", prec, rows, D, K, H, hp, ldh, _ptr(gamma), _ptr(beta), float(eps), _ptr(fc_w), _ptr(fc_b),
           _ptr(x), _ptr(z), float(c1), float(c2), float(c3), int(bool(last)), _ptr(w_fold), _ptr(b_fold), _ptr(vrow), ip, ldp, pp, ldpa,
           _stream())
+
+
+def sampler_tail_proj_cn(prec, h, gamma, beta, fc_w, fc_b, x, seed, counter, row0, c1, c2, c3, last, w_fold, b_fold, vrow, pinv, pa16, eps=1e-5):
+    """sampler_tail_proj that draws the step's noise inside the launch: the values ``sampler_noise(seed, counter, row0, ...)``
+    writes for these rows, without the tensor and without its launch."""
+    hp, rows, D, ldh = as2d(h)
+    pp, rows2, H, ldpa = as2d(pa16, torch.bfloat16)
+    ip, rows3, H3, ldp = as2d(pinv)
+    K = fc_w.shape[0]
+    assert rows == rows2 == rows3 and H3 == H and fc_w.shape == (K, D) and w_fold.shape == (H, K) and fc_w.is_contiguous()
+    assert w_fold.is_contiguous() and b_fold.numel() == H and vrow.numel() == H and vrow.is_contiguous()
+    assert x.is_contiguous() and x.numel() == rows * K
+    _call("tad_sampler_tail_proj_cn_b16", prec, rows, D, K, H, hp, ldh, _ptr(gamma), _ptr(beta), float(eps), _ptr(fc_w), _ptr(fc_b),
+          _ptr(x), int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), int(row0), float(c1), float(c2), float(c3), int(bool(last)),
+          _ptr(w_fold), _ptr(b_fold), _ptr(vrow), ip, ldp, pp, ldpa, _stream())
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
