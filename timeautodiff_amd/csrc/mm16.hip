@@ -30,6 +30,8 @@
 #include <utility>
 
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 #ifndef MM16_ST_AUX
 #define MM16_ST_AUX 0
@@ -499,11 +501,20 @@ struct TnJob {
   int mapH, mapG, slot[4];                                 // gate map of the C rows (mapH == 0: identity)
   int tiles_a, tiles_b, tile_base;
 };
+constexpr int TN_MAXITEMS = 320;               // work items of a launch whose row ranges are sized tile by tile
 struct TnParams {
   int64_t M; int T;
   TnJob job[TN_MAXJOBS]; int njobs;
   int tiles_total, nsplits; int64_t rows_per_split, nitems; int dbg;
+  // balanced = 1: item w is item[w] = tile | split << 10 | (reduction splits of that tile) << 21.  A tile at the edge of
+  // a job multiplies fewer 32-column blocks than a full one and takes less time per row: it gets fewer, longer splits, so
+  // that all items of the launch end together (with the same number of splits for every tile the launch took the time
+  // of its full tiles while the workgroups of the edge tiles idled)
+  int balanced;
+  uint32_t item[TN_MAXITEMS];
 };
+
+static_assert(sizeof(TnParams) <= 4096, "kernel arguments");
 
 __device__ __attribute__((aligned(256))) uint4 g_mm16_zero16[4];      // 16 zero bytes: source of loads that must read as zero
 
@@ -550,8 +561,17 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
     const int64_t xcd = bid % 8, local = bid / 8, q = nw / 8, rem = nw % 8;
     w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
   }
-  const int split = (int)(w / p.tiles_total);
-  const int t = (int)(w % p.tiles_total);
+  int split, t;
+  int64_t rows_per_split = p.rows_per_split;
+  if (p.balanced) {
+    const uint32_t e = p.item[w];
+    t = (int)(e & 1023u); split = (int)((e >> 10) & 2047u);
+    const int64_t slabs = (p.M + TN_BK - 1) / TN_BK, n = (int64_t)(e >> 21);
+    rows_per_split = (slabs + n - 1) / n * TN_BK;
+  } else {
+    split = (int)(w / p.tiles_total);
+    t = (int)(w % p.tiles_total);
+  }
   int ji = 0;
 #pragma unroll
   for (int k = 1; k < TN_MAXJOBS; ++k)
@@ -565,8 +585,12 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
   const int wa = wave & 3, wn = wave >> 2;                     // the two waves of a SIMD share their A columns
   int nblk = (b_end - b_c0 + 31) / 32 - 4 * wn;                // 32-column blocks of B this wave multiplies
   nblk = nblk < 0 ? 0 : nblk > 4 ? 4 : nblk;
-  const int64_t m_beg = (int64_t)split * p.rows_per_split;
-  int64_t m_end = m_beg + p.rows_per_split;
+  // 32-column blocks of A: block wa and block wa + 4 of the tile's eight, so that the blocks of an edge tile spread over
+  // the four SIMDs (with blocks 2 wa, 2 wa + 1 an edge tile of 64 columns kept one SIMD as busy as a full tile does)
+  int nablk = ((a_end - a_c0 + 31) / 32 - wa + 3) / 4;
+  nablk = nablk < 0 ? 0 : nablk > 2 ? 2 : nablk;
+  const int64_t m_beg = (int64_t)split * rows_per_split;
+  int64_t m_end = m_beg + rows_per_split;
   if (m_end > p.M) m_end = p.M;
   const int nslab = (int)((m_end - m_beg + TN_BK - 1) / TN_BK);
   if (nslab <= 0) return;
@@ -630,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
   const uint32_t frow_off = (uint32_t)(uintptr_t)smem + (uint32_t)((8 * (g >> 1) + qq) * 512 + 8 * (pp & 1));
   uint32_t fa[2], fb[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) fa[i] = frow_off + (uint32_t)((4 * ((2 * wa + i) ^ qq) + 2 * (g & 1) + (pp >> 1)) << 4);
+  for (int i = 0; i < 2; ++i) fa[i] = frow_off + (uint32_t)((4 * ((wa + 4 * i) ^ qq) + 2 * (g & 1) + (pp >> 1)) << 4);
 #pragma unroll
   for (int j = 0; j < 4; ++j) fb[j] = frow_off + (uint32_t)((4 * ((4 * wn + j) ^ qq) + 2 * (g & 1) + (pp >> 1)) << 4) + TN_IMG;
 
@@ -643,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j][e] = 0.f;
   }
-  const bool want_db = J.db != nullptr && tb == 0;             // workgroup-uniform; wave (wa, wn) sums A block 2*wa + wn
+  const bool want_db = J.db != nullptr && tb == 0;             // workgroup-uniform; wave (wa, wn) sums A block wa + 4 * wn
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
@@ -657,9 +681,10 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
       if (j < nblk) {
         const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(f.b[j][0], f.b[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+          if (i < nablk) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i][j], 0, 0, 0);
       }
-    if (want_db) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wn ? a[1] : a[0], ones, bacc, 0, 0, 0);
+    if (want_db && wn < nablk) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wn ? a[1] : a[0], ones, bacc, 0, 0, 0);
   };
 
   // Software pipeline over the slabs, one barrier per slab: a wave multiplies slab q from fragments it fetched during
@@ -690,7 +715,9 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
     tn_fetch<0>(aa, ab, f0);
     tn_fetch<16 * 512>(aa, ab, f1);
   };
-  fetch(0);
+  // (a wave of an edge tile with no block pair to multiply and no column sums to form reads no fragments: it refills and meets the barriers)
+  const bool busy = nablk > 0 && (nblk > 0 || (want_db && wn < nablk));
+  if (busy) fetch(0);
   int sq = 0;                              // stage of slab q
 #ifdef MM16_STAMPS
   unsigned long long ts_[12], sum_[12] = {0};
@@ -711,7 +738,7 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
     if (!(p.dbg & 2)) mma(f1);
     __builtin_amdgcn_sched_barrier(0);
     TSTAMP(4);
-    fetch(s1);
+    if (busy) fetch(s1);
     TSTAMP(5);
     if (!(p.dbg & 4)) issue(q + 4, s4);
     TSTAMP(6);
@@ -742,7 +769,7 @@ __global__ __launch_bounds__(512, 2) void mm16_tn_kernel(TnParams p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int na = TN_TA * ta + 64 * wa + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;      // row inside the job's A range
+      const int na = TN_TA * ta + 32 * (wa + 4 * i) + (e & 3) + 8 * (e >> 2) + 4 * h;      // row inside the job's A range
       if (na >= J.na_out) continue;
       const int dst = tn_map_row(J, na);
       if (dst < 0) continue;
@@ -862,6 +889,61 @@ extern "C" int tad_mm16_tn(int64_t M, int64_t T, const void* A16, int64_t lda, i
   p.rows_per_split = cdiv64(slabs, splits) * TN_BK;
   p.nsplits = (int)cdiv64(M, p.rows_per_split);
   p.nitems = (int64_t)p.nsplits * tiles;
+  // Splits sized tile by tile.  Time of a tile per slab of rows ~ alpha (the refill of the slab and the barrier: the same
+  // for every tile) + (1 - alpha) x its share of a full tile's matrix-pipe time: the busiest SIMD multiplies
+  // ceil(A blocks / 4) x (B blocks) of the full tile's 2 x 8 block pairs.
+  static const char* bal_env = getenv("TAD_MM16_TN_BALANCE");      // experiments: 0 = the same number of splits for every tile
+  static const char* alpha_env = getenv("TAD_MM16_TN_ALPHA");
+  const double alpha = alpha_env ? atof(alpha_env) : 0.5;      // (0.45-0.5 measured best at the bench shapes: 248-253 -> 235-240 us per launch)
+  p.balanced = 0;
+  if (!(bal_env && atoi(bal_env) == 0) && tiles <= 1023 && tiles <= target && splits > 1) {
+    std::vector<double> cost((size_t)tiles);
+    double total = 0.0;
+    for (int k = 0; k < njobs; ++k) {
+      const TnJob& j = p.job[k];
+      for (int ta = 0; ta < j.tiles_a; ++ta)
+        for (int tb = 0; tb < j.tiles_b; ++tb) {
+          int nA = (j.na - TN_TA * ta + 31) / 32, nB = (j.nb - TN_TB * tb + 31) / 32;
+          nA = nA > 8 ? 8 : nA; nB = nB > 8 ? 8 : nB;
+          const double c = alpha + (1.0 - alpha) * ((nA + 3) / 4) * nB / 16.0;
+          cost[(size_t)(j.tile_base + ta * j.tiles_b + tb)] = c;
+          total += c;
+        }
+    }
+    const int64_t max_n = std::max<int64_t>(1, slabs / min_slabs);
+    std::vector<int64_t> n((size_t)tiles);
+    int64_t used = 0;
+    for (int t = 0; t < tiles; ++t) {
+      int64_t v = (int64_t)(target * cost[(size_t)t] / total);
+      v = v < 1 ? 1 : v > max_n ? max_n : v;
+      n[(size_t)t] = v; used += v;
+    }
+    // what rounding left over goes, one split at a time, to the tile whose items are the longest
+    while (used < target) {
+      int best = -1; double worst = 0.0;
+      for (int t = 0; t < tiles; ++t) {
+        const double len = cost[(size_t)t] / (double)n[(size_t)t];
+        if (n[(size_t)t] < max_n && len > worst) { worst = len; best = t; }
+      }
+      if (best < 0) break;
+      ++n[(size_t)best]; ++used;
+    }
+    struct It { int64_t m; uint32_t e; };
+    std::vector<It> items;
+    bool fits = true;
+    for (int t = 0; t < tiles && fits; ++t) {
+      const int64_t nt = n[(size_t)t], rps = cdiv64(slabs, nt) * TN_BK;
+      fits = nt <= 2047;
+      for (int64_t sidx = 0; sidx * rps < M && fits; ++sidx) items.push_back(It{sidx * rps, (uint32_t)t | (uint32_t)sidx << 10 | (uint32_t)nt << 21});
+    }
+    if (fits && items.size() <= (size_t)TN_MAXITEMS) {
+      // rows first: the workgroups of an XCD (contiguous runs of items) then share the rows of A and B they fetch
+      std::stable_sort(items.begin(), items.end(), [](const It& x, const It& y) { return x.m < y.m; });
+      for (size_t i = 0; i < items.size(); ++i) p.item[i] = items[i].e;
+      p.nitems = (int64_t)items.size();
+      p.balanced = 1;
+    }
+  }
   { static const char* dbg_env = getenv("TAD_MM16_DBG"); p.dbg = dbg_env ? atoi(dbg_env) : 0; }
   const size_t lds = TN_ST * TN_STAGE;
   static size_t configured[64] = {};

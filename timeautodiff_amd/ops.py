@@ -390,9 +390,9 @@ def mm16_tn(a16, jobs, T=0):
         g6 = (C.c_int32 * 6)(*( (gm[0], gm[1], *gm[2]) if gm is not None else (0, 0, 0, 0, 0, 0)))
         arr[k] = _lib.TnJob(bp, ldb, nb, j.get("shift", 0), cp, ldc, _ptr(j.get("db")), _ptr(j.get("db2")), a0, na, g6, jap, jlda)
         # algorithmic: the rows and columns of C the product fills (a GRU's spare slot and B's zero padding produce
-        # nothing); issued: what the kernel multiplies, its tile padding included
+        # nothing); issued: what the kernel multiplies (whole 32-column blocks of both operands)
         flops += 2.0 * M * n_out * nbc
-        issued += 2.0 * M * (-(-na // TN_TILE_A) * TN_TILE_A) * (-(-nb // 32) * 32)
+        issued += 2.0 * M * (-(-na // 32) * 32) * (-(-nb // 32) * 32)
         bytes_ += 2.0 * M * nb + 4.0 * n_out * nbc
     if a16 is not None:
         bytes_ += 2.0 * M * Na
