@@ -938,6 +938,7 @@ extern "C" int tad_mm16_tn(int64_t M, int64_t T, const void* A16, int64_t lda, i
     }
     if (fits && items.size() <= (size_t)TN_MAXITEMS) {
       // rows first: the workgroups of an XCD (contiguous runs of items) then share the rows of A and B they fetch
+      // (tile-major order fetched 37 % more; with every tile split alike the launch fetched 11 % less and took 7 % longer)
       std::stable_sort(items.begin(), items.end(), [](const It& x, const It& y) { return x.m < y.m; });
       for (size_t i = 0; i < items.size(); ++i) p.item[i] = items[i].e;
       p.nitems = (int64_t)items.size();
