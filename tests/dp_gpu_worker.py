@@ -1,7 +1,9 @@
 """One rank of the data-parallel rehearsal on a single GPU (started by test_y_gpu_dp.py as a fresh process):
 3 steps of DiffusionTrainer and of VAETrainer (+ eval_loss) and one DIFF.sample on a batch that the ranks do not
 divide evenly, with a gloo group holding device tensors.  Rank 0 writes what the test compares.
-usage: python dp_gpu_worker.py RANK WORLD PORT OUT.npz"""
+usage: python dp_gpu_worker.py RANK WORLD PORT OUT.npz [gloo|nccl]
+(nccl with WORLD = 1: a group of one rank over RCCL -- the collectives of the product's backend run, on the streams and with
+the wait semantics they have there, with nobody to exchange with)"""
 import os
 import random
 import sys
@@ -17,9 +19,15 @@ def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     import faulthandler
     faulthandler.dump_traceback_later(120, exit=True)      # a rank that hangs says where, and ends
-    if world > 1:
-        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    pg = True if world > 1 else None
+    backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
+    grouped = world > 1 or backend == "nccl"
+    if grouped:
+        if backend == "nccl":
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pg = True if grouped else None
     from timeautodiff_amd import DIFF, VAE, ops
     dev = torch.device("cuda:0")
     res = {}
@@ -82,7 +90,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         np.savez(out, **res)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -56,3 +56,20 @@ def test_ranks_on_one_gpu_equal_one_process(tmp_path, world, grad_stream):
     assert np.max(np.abs(a["vae_eval"] - b["vae_eval"]) / np.abs(a["vae_eval"])) < 2e-5
     assert _rel(b["vae_grad"], a["vae_grad"]) < 2e-5
     assert _rel(b["vae_w"], a["vae_w"]) < 1e-4
+
+
+@pytest.mark.parametrize("grad_stream", ["0", "1"])
+def test_one_rank_over_rccl_equals_no_group(tmp_path, grad_stream):
+    """The product's backend on the one GPU a test box has: a group of ONE rank over RCCL ("nccl").  Every collective of the
+    trainers and of the sampler (bucketed asynchronous all-reduce of the gradients, the loss and validation sums, the padded
+    all-gather of the sampled sequences) goes through RCCL's streams and its Work.wait(), which differ from gloo's; with
+    nobody to exchange with, the results must equal the run without a group."""
+    worker = os.path.join(HERE, "dp_gpu_worker.py")
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "rccl.npz")
+    env = dict(os.environ, TAD_GRAD_STREAM=grad_stream)
+    subprocess.run([sys.executable, worker, "0", "1", "0", one], check=True, timeout=300, env=env)
+    subprocess.run([sys.executable, worker, "0", "1", str(_port()), two, "nccl"], check=True, timeout=300, env=env)
+    a, b = np.load(one), np.load(two)
+    for k in ("den_loss", "den_grad", "den_w", "sample", "vae_loss", "vae_parts", "vae_eval", "vae_grad", "vae_w"):
+        assert a[k].shape == b[k].shape and _rel(b[k], a[k]) < 1e-6, k
+    assert int(b["sample_local_rows"][0]) == 5
