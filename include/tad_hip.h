@@ -302,8 +302,8 @@ int tad_sampler_update(int64_t n, float* x, const float* pred, const float* z, f
  * tad_sampler_update on x [rows, K] with z [rows, K] (DIFF.py:348-351) -> input_proj of the UPDATED x for the
  * next step (DIFF.py:198; w_in [H, K], b_in [H]) into xh [rows, H] (row stride ldxh).  prec = TAD_BF16 rounds
  * the operands of the two projections to bf16 like the matrix products they replace.  D <= 1024, K <= 8,
- * H <= 1024 and 10 H + 3 + 512 n <= 16384 (the launch's LDS), n = 2, 8 or 16: the least of them that is at least
- * max(D, H) / 64; other shapes take tad_layernorm_fwd + tad_linear_fwd + tad_sampler_update. */
+ * H <= 1024 and 10 H + 3 + 640 n <= 16384 (the launch's LDS), n = 2, 8 or 16: the least of them that is at least
+ * D / 64; other shapes take tad_layernorm_fwd + tad_linear_fwd + tad_sampler_update. */
 int tad_sampler_tail(int prec, int64_t rows, int D, int K, int H, const float* h, int64_t ldh, const float* gamma,
                      const float* beta, float eps, const float* fc_w, const float* fc_b, float* x, const float* z,
                      float c1, float c2, float c3, int last, const float* w_in, const float* b_in, float* xh,

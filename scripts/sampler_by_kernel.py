@@ -4,7 +4,7 @@ import bench
 from timeautodiff_amd import DIFF, ops
 dev = torch.device('cuda:0')
 cx = bench.Ctx(dev, 1, 0) if hasattr(bench, 'Ctx') else None
-for name in ('energy_T24_H200',):
+for name in (sys.argv[1:] or ['energy_T24_H200']):
     wl = bench.WORKLOADS[name]
     schema = wl['schema']
     F_ = schema['n_bins'] + schema['n_cats'] + schema['n_nums']

@@ -416,8 +416,10 @@ struct TailNoise {
 // A row costs its instructions, not its bytes (the first form ran 2400 per row, most of them lane masks and scalar
 // guards of the unrolled loops): every load of a row is issued at the top of its iteration through clamped addresses
 // (no branch around a load), the two weight matrices sit in LDS padded to 8 values per column, read 16 bytes at a time,
-// loops over the K outputs have no guards where K is the template's KT (KT = 0: any K <= 8, guarded).
-template <int NC, int KT>
+// loops over the K outputs have no guards where K is the template's KT (KT = 0: any K <= 8, guarded).  What a lane keeps
+// per row is what it must (the row, double-buffered, and NP = ceil(H / 64) values of the next projection's step-invariant
+// share): LayerNorm's weights are read from LDS too, so that four waves per SIMD stay resident at D = 1024.
+template <int NC, int KT, int NP>
 __global__ __launch_bounds__(EW_BLOCK) void sampler_tail_kernel(int64_t rows, int D, int K, int H, int round16, const float* __restrict__ h, int64_t ldh,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                     const float* __restrict__ fcw, const float* __restrict__ fcb, float* __restrict__ x,
@@ -428,13 +430,16 @@ __global__ __launch_bounds__(EW_BLOCK) void sampler_tail_kernel(int64_t rows, in
   constexpr int KMAX = 8;
   constexpr int KN = KT ? KT : KMAX;           // trip count of the loops over the outputs
   extern __shared__ __attribute__((aligned(16))) float tail_lds[];
-  // LDS: w_in [H][8] (rounded, zeros beyond K), b_in [H], vrow [H], fc's weight [64 NC][8] (rounded, zeros beyond K and D).
+  // LDS: w_in [H][8] (rounded, zeros beyond K), b_in [H], vrow [H], fc's weight [64 NC][8] (rounded, zeros beyond K and D),
+  // LayerNorm's gamma and beta [64 NC] each (zeros beyond D).
   // pinv != NULL: w_in / b_in are the input projection folded into the x share of `proj` (prepared by the caller from
   // rounded factors: not rounded again) and the row leaves as relu(. + vrow + pinv[r]), the operand of the LSTM's input side
   float* const win = tail_lds;
   float* const bin = tail_lds + (size_t)H * KMAX;
   float* const vr = bin + H;
   float* const fw = vr + H + ((4 - ((2 * H) & 3)) & 3);      // 16-byte aligned
+  float* const gml = fw + 64 * NC * KMAX;
+  float* const btl = gml + 64 * NC;
   // (the fills keep eight loads per thread in flight through clamped addresses: a branch around each load made the
   // prologue of a workgroup a chain of sixteen round trips to L2, half of the launch's time)
   auto fill = [&](float* dst, int n, auto value) {
@@ -467,25 +472,21 @@ __global__ __launch_bounds__(EW_BLOCK) void sampler_tail_kernel(int64_t rows, in
     const float wr = round16 ? (float)(bf16_t)w : w;
     return (c < D && k < K) ? wr : 0.f;
   });
+  fill(gml, 64 * NC, [&](int c) { const float v = gamma[c < D ? c : D - 1]; return c < D ? v : 0.f; });
+  fill(btl, 64 * NC, [&](int c) { const float v = beta[c < D ? c : D - 1]; return c < D ? v : 0.f; });
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int nD = (D + 63) >> 6, nH = (H + 63) >> 6;        // 64-column blocks of a row that exist
-  float gm[NC], bt[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = lane + 64 * i, cc = c < D ? c : D - 1;
-    const float g_ = gamma[cc], b_ = beta[cc];
-    gm[i] = c < D ? g_ : 0.f;
-    bt[i] = c < D ? b_ : 0.f;
-  }
+  // (the wave's index through readfirstlane: row addresses are then scalar bases with 32-bit lane offsets, not 64-bit
+  // per-lane pointers -- two registers and an add per load less)
+  const int64_t wave = (int64_t)blockIdx.x * (EW_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t nwaves = (int64_t)gridDim.x * (EW_BLOCK / 64);
+  const int nD = (D + 63) >> 6, nH = (H + 63) >> 6;        // 64-column blocks of a row that exist (nH <= NP)
   const int kl = lane < K ? lane : K - 1;
   const float fcb_l = fcb[kl];
   // The loads of row r + nwaves are issued before row r's stores: the wait for loaded values releases in issue order, so
   // loads issued behind the stores would wait for the stores' acknowledgements too (a row then took its store latency, its
   // load latency and its arithmetic one after the other: 5 us).
-  float xq[NC], pq[NC], xo_q, z_q;
+  float xq[NC], pq[NP], xo_q, z_q;
   auto fetch = [&](int64_t rr) {
     if (rr >= rows) rr = rows - 1;               // (uniform; the values are not used)
     const float* hr = h + rr * ldh;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(EW_BLOCK) void sampler_tail_kernel(int64_t rows, in
     xo_q = x[rr * K + kl];
     z_q = nz.on ? 0.f : z[rr * K + kl];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
+    for (int i = 0; i < NP; ++i) {
       const int u = lane + 64 * i;
       pq[i] = (pinv && i < nH) ? pinv[rr * ldp + (u < H ? u : H - 1)] : 0.f;
     }
@@ -510,9 +511,11 @@ __global__ __launch_bounds__(EW_BLOCK) void sampler_tail_kernel(int64_t rows, in
   float zbatch = 0.f;
   int jj = 0;                                    // the row's place in its batch
   for (int64_t r = wave; r < rows; r += nwaves) {
-    float xv[NC], pv[NC];
+    float xv[NC], pv[NP];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) { xv[i] = xq[i]; pv[i] = pq[i]; }
+    for (int i = 0; i < NC; ++i) xv[i] = xq[i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pv[i] = pq[i];
     const float x_old = xo_q;
     float zv = z_q;
     fetch(r + nwaves);
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(EW_BLOCK) void sampler_tail_kernel(int64_t rows, in
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       if (i < nD) {
-        float y = (xv[i] - mean) * rstd * gm[i] + bt[i];
+        float y = (xv[i] - mean) * rstd * gml[lane + 64 * i] + btl[lane + 64 * i];
         if (round16) y = (float)(bf16_t)y;
         if (lane + 64 * i >= D) y = 0.f;
         const float4 w0 = *reinterpret_cast<const float4*>(fw + (size_t)(lane + 64 * i) * KMAX);
@@ -554,6 +557,8 @@ __global__ __launch_bounds__(EW_BLOCK) void sampler_tail_kernel(int64_t rows, in
 #pragma unroll
         for (int k = 0; k < KN; ++k) acc[k] += y * w8[k];
       }
+      // (wide rows: the weights of four column blocks at a time, not of all sixteen, wait in registers)
+      if constexpr (NC > 8) { if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
     }
     float pk = 0.f;                              // lane k < K: the row's prediction k (before the bias)
 #pragma unroll
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(EW_BLOCK) void sampler_tail_kernel(int64_t rows, in
       xn[k] = round16 ? (float)(bf16_t)t : t;
     }
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
+    for (int i = 0; i < NP; ++i) {
       if (i < nH) {
         const int u = lane + 64 * i, uc = u < H ? u : H - 1;
         const float4 w0 = *reinterpret_cast<const float4*>(win + (size_t)uc * KMAX);
@@ -1079,21 +1084,18 @@ static int sampler_tail(int prec, int64_t rows, int D, int K, int H, const float
   if (rows == 0) return TAD_OK;
   int64_t g = cdiv64(rows, EW_BLOCK / 64);
   if (g > 512) g = 512;          // two workgroups per CU: the prologue (weights into LDS) is a third of a 25 k-row launch
-  int nc = (int)cdiv64(D > H ? D : H, 64);          // a lane's columns cover the recurrent output and the projection
+  int nc = (int)cdiv64(D, 64);                      // 64-column blocks of the recurrent output a lane holds
   nc = nc <= 2 ? 2 : nc <= 8 ? 8 : 16;
-  const size_t lds = sizeof(float) * ((size_t)H * 10 + 3 + (size_t)8 * 64 * nc);
-  TAD_CHECK(lds <= 65536, "tad_sampler_tail: 10 H + 512 ceil(max(D, H) / 64) exceeds the launch's LDS (D=%d K=%d H=%d)", D, K, H);
+  const int nh = (int)cdiv64(H, 64);                // ... of the projection: half of nc in the reference's models (D = 2 H)
+  const size_t lds = sizeof(float) * ((size_t)H * 10 + 3 + (size_t)10 * 64 * nc);
+  TAD_CHECK(lds <= 65536, "tad_sampler_tail: 10 H + 640 n exceeds the launch's LDS (D=%d K=%d H=%d)", D, K, H);
   const int r16 = prec == TAD_BF16 ? 1 : 0;
-#define TAIL(NC, KT) hipLaunchKernelGGL((sampler_tail_kernel<NC, KT>), dim3((unsigned)g), dim3(EW_BLOCK), lds, EW_STREAM, rows, D, K, H, r16, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, nz, c1, c2, c3, last, w_in, b_in, xh, ldxh, xh16, vrow, pinv, ldp)
-  if (K == 6) {          // (the latent width of every reference notebook)
-    if (nc == 2) TAIL(2, 6);
-    else if (nc == 8) TAIL(8, 6);
-    else TAIL(16, 6);
-  } else {
-    if (nc == 2) TAIL(2, 0);
-    else if (nc == 8) TAIL(8, 0);
-    else TAIL(16, 0);
-  }
+#define TAIL(NC, KT, NP) hipLaunchKernelGGL((sampler_tail_kernel<NC, KT, NP>), dim3((unsigned)g), dim3(EW_BLOCK), lds, EW_STREAM, rows, D, K, H, r16, h, ldh, gamma, beta, eps, fc_w, fc_b, x, z, nz, c1, c2, c3, last, w_in, b_in, xh, ldxh, xh16, vrow, pinv, ldp)
+#define TAIL_K(NC, NP) do { if (K == 6) TAIL(NC, 6, NP); else TAIL(NC, 0, NP); } while (0)      /* (6: the latent width of every reference notebook) */
+  if (nc == 2) { if (nh <= 1) TAIL_K(2, 1); else TAIL_K(2, 16); }
+  else if (nc == 8) { if (nh <= 4) TAIL_K(8, 4); else TAIL_K(8, 16); }
+  else { if (nh <= 8) TAIL_K(16, 8); else TAIL_K(16, 16); }
+#undef TAIL_K
 #undef TAIL
   TAD_LAUNCH_CHECK();
   return TAD_OK;

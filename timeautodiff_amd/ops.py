@@ -787,9 +787,9 @@ def flip_categories(cond, cols, classes, rnd, base, p, out):
 
 
 def sampler_tail_supported(D, K, H):
-    nc = -(-max(D, H) // 64)
+    nc = -(-D // 64)
     nc = 2 if nc <= 2 else 8 if nc <= 8 else 16
-    return D <= 1024 and K <= 8 and H <= 1024 and 10 * H + 3 + 512 * nc <= 16384
+    return D <= 1024 and K <= 8 and H <= 1024 and 10 * H + 3 + 640 * nc <= 16384
 
 
 def sampler_tail(prec, h, gamma, beta, fc_w, fc_b, x, z, c1, c2, c3, last, w_in, b_in, xh, eps=1e-5):
