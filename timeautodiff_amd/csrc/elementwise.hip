@@ -356,7 +356,7 @@ __global__ void layernorm_fwd_kernel(int64_t rows, int D, const float* __restric
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                      float* __restrict__ y, int64_t ldy, float* __restrict__ mr) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // scalar: row addresses = scalar base + lane offset
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   float gm[NC], bt[NC];
 #pragma unroll
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_fc_fwd_kernel(int64_t rows, int D
                                  const float* __restrict__ fcw, const float* __restrict__ fcb, float* __restrict__ y, int64_t ldy,
                                  float* __restrict__ mr, float* __restrict__ pred) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // scalar: row addresses = scalar base + lane offset
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   float gm[NC], bt[NC], wk[KMAX][NC];
 #pragma unroll
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_fc_bwd_kernel(int64_t rows, int D
                                  float* __restrict__ dfcw, float* __restrict__ dfcb) {
   extern __shared__ float lnfc_red[];              // DW ? [KMAX][NC * 64] : [2][NC * 64]
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nwb = blockDim.x >> 6;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // scalar: row addresses = scalar base + lane offset
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   constexpr int NA = DW ? KMAX : 2;
   float acc[NA][NC], gm[NC], bt[NC], wk[DW ? 1 : KMAX][NC], dbk[KMAX];
@@ -824,7 +824,7 @@ __global__ void layernorm_bwd_kernel(int64_t rows, int D, const float* __restric
                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float red[2][NC * 64];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nwb = blockDim.x >> 6;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // scalar: row addresses = scalar base + lane offset
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   float dg[NC], db[NC], gm[NC];
 #pragma unroll
