@@ -167,6 +167,20 @@ def test_mm16_tn_job_lists(ops, dev, M, T):
         _tn(ops, dev, M, 64, [(0, 64, 24, 0, gru_in, True), (0, 32, 8, -1, gru_hid, True), (32, 32, 8, 1, gru_hid, True)], T=T)
 
 
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+def test_mm16_tn_recurrent_layer_launch_at_model_width(ops, dev, cell):
+    """The weight-gradient launch of a recurrent layer at the bench model's widths (H = 200: A has 1600 columns = 6 tiles
+    and a quarter, the recurrent jobs 800 = 3 tiles and an eighth, B 400 / 200 columns), with enough rows that the reduction
+    is split and the splits are sized tile by tile: gate maps, time shifts and bias sums through the edge tiles."""
+    H, T, M = 200, 24, 24576
+    if cell == "lstm":
+        gi = gh = (H, 4, (0, 1, 2, 3))
+    else:
+        gi, gh = (H, 3, (0, 1, 2, -1)), (H, 3, (0, 1, -1, 2))
+    _tn(ops, dev, M, 1600, [(0, 1600, 400, 0, gi, True), (0, 800, 200, -1, gh, True), (800, 800, 200, 1, gh, False)], T=T)
+    _tn(ops, dev, M, 1600, [(0, 1600, 128, 0, gi, True), (0, 800, 200, -1, gh, False), (800, 800, 200, 1, gh, True)], T=T)
+
+
 def test_mm16_tn_accumulates_and_rejects(ops, dev):
     A = torch.ones(64, 8, device=dev, dtype=torch.bfloat16)
     B = torch.ones(64, 8, device=dev, dtype=torch.bfloat16)
