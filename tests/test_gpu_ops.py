@@ -1129,7 +1129,7 @@ def test_sampler_tail_equals_the_four_launches(ops, dev, prec, shape):
     assert torch.all(xhb._base[:, H:] == 7.0)
 
 
-@pytest.mark.parametrize("rows,Dm,K,H,last", [(300, 400, 6, 200, False), (70, 1024, 6, 512, True), (33, 256, 8, 128, False), (45, 128, 5, 64, True)])
+@pytest.mark.parametrize("rows,Dm,K,H,last", [(300, 400, 6, 200, False), (70, 1024, 6, 512, True), (33, 256, 8, 128, False), (45, 128, 5, 64, True), (50, 128, 6, 200, False), (40, 512, 6, 384, True)])
 def test_sampler_tail_with_folded_proj_share(ops, dev, rows, Dm, K, H, last):
     """tad_sampler_tail_proj_b16 -- the tail of a reverse step that also leaves relu(x_new (W_1 W_in)^T + W_1 b_in + V[s] +
     pinv), the LSTM's operand of the NEXT step -- against the two launches it replaces (tad_sampler_tail_b16, then the
