@@ -871,14 +871,16 @@ def test_vae_reparam(ops, dev):
     assert fu.rel_err(dlv.cpu().numpy(), dz * eps * 0.5 * np.exp(0.5 * lv) - 0.15 * (1 - np.exp(lv))) < 1e-5
 
 
-@pytest.mark.parametrize("schema", ["numeric", "mixed", "metro"])
-def test_vae_heads_loss(ops, dev, schema):
+@pytest.mark.parametrize("schema,B,T", [("numeric", 6, 5), ("mixed", 6, 5), ("metro", 6, 5), ("mixed", 301, 17), ("metro", 257, 24), ("mixed", 2100, 24),
+                                        ("manycats", 40, 7)])
+def test_vae_heads_loss(ops, dev, schema, B, T):
+    """(The launch has two forms: one thread per head column for up to eight categorical features and 256 head columns --
+    several row groups per workgroup from 1024 x 7 rows on -- and one thread per row beyond: `manycats` takes the second.)"""
     from oracle import vae as ovae
     from oracle.denoiser import Schema
-    s = fu.SCHEMAS[schema]
+    s = fu.SCHEMAS[schema] if schema != "manycats" else dict(n_bins=1, n_cats=9, n_nums=2, cards=[3, 2, 4, 5, 2, 3, 6, 2, 4])
     sch = Schema(s["n_bins"], s["n_cats"], s["n_nums"], list(s["cards"]))
     rng = np.random.default_rng(12)
-    B, T = 6, 5
     rows = B * T
     data = fu.make_data(s, N=B, T=T, K=4, seed=5, mask_kind="bern")
     F = data["data"].shape[-1]
