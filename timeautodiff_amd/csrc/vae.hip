@@ -260,7 +260,7 @@ extern "C" int tad_vae_heads_loss(int64_t rows, int nb, int nc, int nn, const in
   }
   TAD_CHECK(ldh >= nh && ldf >= nb + nc + nn, "tad_vae_heads_loss: bad leading dimension");
   if (rows == 0) return TAD_OK;
-  if (nh <= VB && nc <= 8) {
+  if (nh >= 1 && nh <= VB && nc <= 8) {
     // (up to eight categorical features: their loss sums are one workgroup reduction each)
     const int rpb = (int)(VB / nh);
     int64_t grid = cdiv64(rows, rpb);
