@@ -698,22 +698,47 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_fc_bwd_kernel(int64_t rows, int D
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // scalar: row addresses = scalar base + lane offset
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   constexpr int NA = DW ? KMAX : 2;
-  float acc[NA][NC], gm[NC], bt[NC], wk[DW ? 1 : KMAX][NC], dbk[KMAX];
+  // (rows of more than 512 columns, first role: gamma, beta and the projection's weights in LDS behind the reduction
+  // rows, as in the forward -- the role ran one wave per SIMD on 283 registers)
+  constexpr bool WL = NC > 8 && !DW;
+  constexpr int WW = NC * 64;
+  float* const lw = lnfc_red + NA * WW;            // WL: [KMAX + 2][WW]
+  float acc[NA][NC], gm[WL ? 1 : NC], bt[WL ? 1 : NC], wk[(DW || WL) ? 1 : KMAX][WL ? 1 : NC], dbk[KMAX];
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
-    const int c = lane + 64 * i;
-    gm[i] = c < D ? gamma[c] : 0.f;
-    bt[i] = c < D ? beta[c] : 0.f;
 #pragma unroll
     for (int a = 0; a < NA; ++a) acc[a][i] = 0.f;
-    if constexpr (!DW) {
+  }
+  if constexpr (WL) {
+    for (int e = threadIdx.x; e < (KMAX + 2) * WW; e += blockDim.x) {
+      const int k = e / WW, c = e - k * WW;
+      float v = 0.f;
+      if (c < D) {
+        if (k < K) { v = fcw[(int64_t)k * D + c]; if (round16) v = (float)(bf16_t)v; }
+        else if (k == KMAX) v = gamma[c];
+        else if (k == KMAX + 1) v = beta[c];
+      }
+      lw[e] = v;
+    }
+    __syncthreads();
+  } else {
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        const float w = (c < D && k < K) ? fcw[(int64_t)k * D + c] : 0.f;
-        wk[k][i] = round16 ? (float)(bf16_t)w : w;
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      gm[i] = c < D ? gamma[c] : 0.f;
+      bt[i] = c < D ? beta[c] : 0.f;
+      if constexpr (!DW) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          const float w = (c < D && k < K) ? fcw[(int64_t)k * D + c] : 0.f;
+          wk[k][i] = round16 ? (float)(bf16_t)w : w;
+        }
       }
     }
   }
+  auto GM = [&](int i) -> float { if constexpr (WL) return lw[KMAX * WW + lane + 64 * i]; else return gm[i]; };
+  auto BT = [&](int i) -> float { if constexpr (WL) return lw[(KMAX + 1) * WW + lane + 64 * i]; else return bt[i]; };
+  auto WK = [&](int k, int i) -> float { if constexpr (WL) return lw[k * WW + lane + 64 * i]; else return wk[k][i]; };
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) dbk[k] = 0.f;
   // operands of the wave's next row, fetched before the current row is worked on (see the forward)
@@ -753,15 +778,15 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_fc_bwd_kernel(int64_t rows, int D
       if (c < D) {
         xh[i] = (xcur[i] - mean) * rstd;
         if constexpr (DW) {
-          float yv = xh[i] * gm[i] + bt[i];
+          float yv = xh[i] * GM(i) + BT(i);
           if (round16) yv = (float)(bf16_t)yv;
 #pragma unroll
           for (int k = 0; k < KMAX; ++k) acc[k][i] += dpq[k] * yv;
         } else {
           float g = 0.f;
 #pragma unroll
-          for (int k = 0; k < KMAX; ++k) g += dpq[k] * wk[k][i];
-          dxh[i] = g * gm[i];
+          for (int k = 0; k < KMAX; ++k) g += dpq[k] * WK(k, i);
+          dxh[i] = g * GM(i);
           acc[0][i] += g * xh[i];
           acc[1][i] += g;
           s1 += dxh[i];
@@ -1428,7 +1453,7 @@ extern "C" int tad_ln_fc_bwd(int prec, int64_t rows, int D, int K, const float* 
   if (g > cap) g = cap;
   if (g2 > cap2) g2 = cap2;
   const int r16 = prec == TAD_BF16 ? 1 : 0;
-#define LNFC(NC, DWV, G, NAV) hipLaunchKernelGGL((ln_fc_bwd_kernel<NC, 8, DWV>), dim3((unsigned)(G)), dim3(EW_BLOCK), sizeof(float) * (NAV) * NC * 64, EW_STREAM, rows, D, K, r16, dpred, x, ldx, gamma, beta, mean_rstd, fc_w, dx, lddx, dgamma, dbeta, dfc_w, dfc_b)
+#define LNFC(NC, DWV, G, NAV) hipLaunchKernelGGL((ln_fc_bwd_kernel<NC, 8, DWV>), dim3((unsigned)(G)), dim3(EW_BLOCK), sizeof(float) * ((NAV) + ((NC > 8 && !DWV) ? 10 : 0)) * NC * 64, EW_STREAM, rows, D, K, r16, dpred, x, ldx, gamma, beta, mean_rstd, fc_w, dx, lddx, dgamma, dbeta, dfc_w, dfc_b)
   if (D <= 128) { LNFC(2, false, g, 2); LNFC(2, true, g2, 8); }
   else if (D > 384 && D <= 448) { LNFC(7, false, g, 2); LNFC(7, true, g2, 8); }
   else if (D <= 512) { LNFC(8, false, g, 2); LNFC(8, true, g2, 8); }
