@@ -255,6 +255,26 @@ int tad_rnn_fwd_ws(int cell, int prec, int store, int64_t B, int64_t T, int64_t 
                    void* workspace, int64_t workspace_bytes, tad_stream_t stream);
 int tad_rnn_ws_status(const void* workspace, tad_stream_t stream);
 
+/* tad_rnn_fwd_ws for a layer whose input is narrow (at most 32 columns: the first layer of the VAE's two encoder GRUs reads
+ * the table's features, VAE.py:119-120 -> 154-155): the cluster form then multiplies x_t by its slice of W_ih itself, and
+ * the input-side pre-activations [B*T, 4H] are neither written nor read (dirs[i].xproj is ignored and may be NULL).
+ * Per direction: x16 = the layer's input [B*T, kin] bf16 (row stride ldx, a multiple of 8; 16-byte aligned; kin = 8, 16, 24
+ * or 32), w_ih16 = the gate-interleaved bf16 image of W_ih that tad_rnn_pack_input writes ([4H, ldw], ldw >= 32, zeros
+ * in columns kin..31), bias = tad_rnn_pack_input's bias_gl [4H].  The pre-activations are not rounded to bf16 on the way
+ * to the gates as they are in a stored xproj; everything else as tad_rnn_fwd_ws.  Where the cluster form does not apply
+ * (see tad_rnn_fwd_ws) the call fails with TAD_ERR_INVALID: the caller forms xproj and calls tad_rnn_fwd_ws. */
+typedef struct {
+  const void* x16;
+  int64_t ldx;
+  const void* w_ih16;
+  int64_t ldw;
+  const float* bias;
+  int32_t kin;
+  int32_t pad_;
+} tad_rnn_xin_t;
+int tad_rnn_fwd_ws_x(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
+                     const tad_rnn_xin_t* xin, void* workspace, int64_t workspace_bytes, tad_stream_t stream);
+
 /* Bytes of ONE packed buffer (forward or backward) of a recurrent weight matrix W_hh[G*H,H].  In bf16 precision
  * the forward buffer holds up to three images: the one the 32-row MFMA forms read, behind it the one of the 16-row form
  * that launches of 8 batch rows per workgroup take, and at H = 512 the one of tad_rnn_fwd_ws's cluster form (every reverse step of `sample`, DIFF.py:340-351, at up to 2047

@@ -36,6 +36,10 @@ _ROUND_OPERANDS = False
 # path does so for every layer with an even hidden size (an input width that is not a multiple of 8 is padded
 # with zero columns there, which changes no value).
 _ROUND_STORAGE = False
+# ... except the input-side pre-activations of a layer whose sequence kernel forms them on chip (the HIP path's first
+# encoder layer of the VAE at hidden size 512 reads at most 32 input columns and multiplies them itself): they reach the
+# gates unrounded (``with rnn_xproj_on_chip():`` inside the above).
+_XPROJ_ON_CHIP = False
 
 
 def bf16_round(a):
@@ -58,6 +62,22 @@ class bf16_operands:
     def __exit__(self, *exc):
         global _ROUND_OPERANDS, _ROUND_STORAGE
         _ROUND_OPERANDS, _ROUND_STORAGE = self.prev
+
+
+class rnn_xproj_on_chip:
+    def __enter__(self):
+        global _XPROJ_ON_CHIP
+        self.prev = _XPROJ_ON_CHIP
+        _XPROJ_ON_CHIP = True
+
+    def __exit__(self, *exc):
+        global _XPROJ_ON_CHIP
+        _XPROJ_ON_CHIP = self.prev
+
+
+def rnn_xproj_store_bf16(H, in_dim):
+    """True if a recurrent layer of this shape reads its input-side pre-activations back from bf16 storage."""
+    return rnn_store_bf16(H, in_dim) and not _XPROJ_ON_CHIP
 
 
 def rnn_store_bf16(H, in_dim):

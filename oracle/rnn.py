@@ -5,9 +5,11 @@ documented convention (gate rows stacked [i;f;g;o] for LSTM and [r;z;n] for
 GRU), which is what the reference's ``nn.LSTM`` (DIFF.py:182) and ``nn.GRU``
 (DIFF.py:189, VAE.py:119-120) evaluate.
 """
+import contextlib
+
 import numpy as np
 
-from .ops import mm, rnn_store_bf16, sigmoid, stored
+from .ops import mm, rnn_store_bf16, rnn_xproj_on_chip, rnn_xproj_store_bf16, sigmoid, stored
 
 
 def _sfx(layer, reverse):
@@ -20,7 +22,7 @@ def lstm_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
     H = Whh.shape[1]
     dt = x.dtype
     s16 = rnn_store_bf16(H, x.shape[-1])
-    xp = stored(mm(x, Wih.T) + (bih + bhh), s16)
+    xp = stored(mm(x, Wih.T) + (bih + bhh), rnn_xproj_store_bf16(H, x.shape[-1]))
     h = np.zeros((B, H), dt)
     c = np.zeros((B, H), dt)
     hs = np.zeros((B, T, H), dt)
@@ -86,7 +88,7 @@ def gru_dir_fwd(x, Wih, Whh, bih, bhh, reverse):
     H = Whh.shape[1]
     dt = x.dtype
     s16 = rnn_store_bf16(H, x.shape[-1])
-    xp = stored(mm(x, Wih.T) + bih, s16)
+    xp = stored(mm(x, Wih.T) + bih, rnn_xproj_store_bf16(H, x.shape[-1]))
     h = np.zeros((B, H), dt)
     hs = np.zeros((B, T, H), dt)
     stash = np.zeros((B, T, 4 * H), dt)       # r, z, n, hp_n
@@ -154,10 +156,15 @@ def rnn_fwd(kind, sd, prefix, x, num_layers, bidirectional):
     for layer in range(num_layers):
         outs = []
         lc = []
+        # storage emulation: the HIP path's first layer at hidden size 512 multiplies an input of at most 32 columns
+        # inside its sequence kernel, so these pre-activations see no bf16 storage
+        H = sd[prefix + "weight_hh" + _sfx(0, False)].shape[1]
+        on_chip = layer == 0 and H == 512 and inp.shape[-1] <= 32
         for rev in ([False, True] if bidirectional else [False]):
             s = _sfx(layer, rev)
-            hs, cache = fwd(inp, sd[prefix + "weight_ih" + s], sd[prefix + "weight_hh" + s],
-                            sd[prefix + "bias_ih" + s], sd[prefix + "bias_hh" + s], rev)
+            with (rnn_xproj_on_chip() if on_chip else contextlib.nullcontext()):
+                hs, cache = fwd(inp, sd[prefix + "weight_ih" + s], sd[prefix + "weight_hh" + s],
+                                sd[prefix + "bias_ih" + s], sd[prefix + "bias_hh" + s], rev)
             outs.append(hs)
             lc.append(cache)
         inp = np.concatenate(outs, -1) if bidirectional else outs[0]

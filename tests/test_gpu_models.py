@@ -694,6 +694,9 @@ def test_vae_at_baseline_model_dimensions_vs_oracle(dev, name, dtype):
     Bernoulli(0.1) int32 point mask) and energy (1 categorical of 8 + 27 numericals, T = 24) schemas: latents, heads,
     the masked mixed loss and every gradient against the oracle -- fp32 1e-4; bf16 against the bf16-emulating oracle."""
     sd_, _, T, B, Hv, mk = BASELINE_SHAPES[name]
+    # (Metro: 4 windows.  With 3 and these seeds one pre-activation of the decoder's first ReLU lies within a bf16 step of
+    # zero: the fp32 summation order decides its mask, and with it 2 % of the embedding gradients, between device and oracle.)
+    B = 4 if name == "metro_T48_H512" else B
     sch = Schema(sd_["n_bins"], sd_["n_cats"], sd_["n_nums"], list(sd_["cards"]))
     L, E, beta = 6, 128, 0.05
     meta = dict(H=Hv, E=E, L=L, seed=95)

@@ -233,7 +233,7 @@ IN_SLOTS = {0: (0, 1, 2, 3), 1: (0, 1, 2, -1)}
 HID_SLOTS = {0: (0, 1, 2, 3), 1: (0, 1, -1, 2)}
 
 
-def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11, cluster=False):
+def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11, cluster=False, xin=False):
     """One layer, len(rev_flags) directions sharing the input, through the C ABI exactly as the engine drives
     it: pack -> input GEMM -> sequence kernel -> BPTT kernel -> weight / bias / input gradients.  bf16 storage
     of the per-timestep tensors is used when the shapes allow it (H even, IN a multiple of 8).
@@ -252,7 +252,8 @@ def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11, cluster=False
     bhh = rng.uniform(-k, k, (nd, GH)).astype(np.float32)
     oracle = []
     fwd, bwd = (ornn.lstm_dir_fwd, ornn.lstm_dir_bwd) if cell == 0 else (ornn.gru_dir_fwd, ornn.gru_dir_bwd)
-    with (oops.bf16_operands(storage=True) if prec else contextlib.nullcontext()):
+    with (oops.bf16_operands(storage=True) if prec else contextlib.nullcontext()), \
+            (oops.rnn_xproj_on_chip() if xin else contextlib.nullcontext()):
         for d, rev in enumerate(rev_flags):
             f64 = lambda a: a.astype(np.float64)
             hs, cache = fwd(f64(x), f64(Wih[d]), f64(Whh[d]), f64(bih[d]), f64(bhh[d]), rev)
@@ -261,9 +262,11 @@ def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11, cluster=False
     # device
     xd, doutd = D(x, dev).view(BT, IN), D(dout, dev).view(BT, nd * H)
     Wihd, Whhd, bihd, bhhd = D(Wih, dev), D(Whh, dev), D(bih, dev), D(bhh, dev)
-    w_gl = torch.empty(nd * H4, IN, dtype=sdt, device=dev)
+    # (xin: the sequence kernel reads 32 columns of the image whatever the input width)
+    w_gl = torch.empty(nd * H4, 128 if xin else IN, dtype=sdt, device=dev)
     bias_gl = torch.empty(nd * H4, device=dev)
     ops.rnn_pack_input(cell, H, Wihd.view(nd * GH, IN), bihd.view(-1), bhhd.view(-1), w_gl, bias_gl)
+    w_gl = w_gl[:, :IN]
     xproj = torch.zeros(BT, nd * H4, dtype=sdt, device=dev)
     if s16:
         ops.linear_fwd_b16(xd, w_gl, bias_gl, xproj)
@@ -290,13 +293,27 @@ def _run_rnn(ops, dev, cell, prec, B, T, H, rev_flags, rng, IN=11, cluster=False
         nws = ops.rnn_workspace_bytes(cell, prec, 1 if s16 else 0, B, T, H, nd)
         assert nws > 0
         wsp = torch.zeros(nws, dtype=torch.uint8, device=dev)
-        ops.rnn_fwd(cell, prec, B, T, H, fdirs, workspace=wsp)
+        xi = None
+        if xin:
+            # the layer's input as bf16 (a padded row stride), W_ih and the bias from the gate-interleaved images; no xproj
+            x16 = torch.zeros(BT, IN + 8, dtype=torch.bfloat16, device=dev)[:, :IN]
+            x16.copy_(xd)
+            xi = [dict(x16=x16, w_ih16=w_gl[d * H4:(d + 1) * H4], bias=bias_gl[d * H4:(d + 1) * H4]) for d in range(nd)]
+            stored_h = None
+            if B * T <= 4096:
+                ops.rnn_fwd(cell, prec, B, T, H, fdirs, workspace=wsp)       # from the stored pre-activations, for comparison
+                stored_h = out.clone()
+                out.zero_(); gates.zero_(); cst.zero_()
+            fdirs = [dict(d, xproj=None) for d in fdirs]
+        ops.rnn_fwd(cell, prec, B, T, H, fdirs, workspace=wsp, xin=xi)
         fwd_kernel = ops._lib.load().tad_last_kernel().decode()
         ops.rnn_ws_status(wsp)
+        if xin and stored_h is not None:
+            assert fu.rel_err(out.cpu().numpy(), stored_h.cpu().numpy()) < BF16_EMU_TOL
         # and once more without the stash (inference): the same h
         out_inf = torch.zeros_like(out)
         idirs = [dict(d, gates=None, cstate=None, out=out_inf[:, k * H:(k + 1) * H]) for k, d in enumerate(fdirs)]
-        ops.rnn_fwd(cell, prec, B, T, H, idirs, workspace=wsp)
+        ops.rnn_fwd(cell, prec, B, T, H, idirs, workspace=wsp, xin=xi)
         ops.rnn_ws_status(wsp)
         assert torch.equal(out_inf, out)
     else:
@@ -404,6 +421,45 @@ def test_rnn_cluster_form_at_hidden_512(ops, dev, cell, B, T, revs):
     r = _run_rnn(ops, dev, cell, 1, B, T, H, list(revs), rng, IN=IN, cluster=True)
     assert r["s16"] and r["fwd_kernel"].startswith("rnn_cluster_fwd_kernel"), r["fwd_kernel"]
     _check_rnn(r, cell, B, T, H, BF16_EMU_TOL)
+
+
+@pytest.mark.parametrize("B,T,IN,revs", [(4100, 3, 8, (False, False)), (300, 5, 32, (False, False)), (100, 6, 24, (False, True)),
+                                         (70, 4, 16, (True,)), (1, 2, 8, (False,)), (129, 2, 32, (False, False))])
+@pytest.mark.parametrize("cell", [0, 1])
+def test_rnn_cluster_form_multiplies_a_narrow_input_itself(ops, dev, cell, B, T, IN, revs):
+    """tad_rnn_fwd_ws_x: a layer input of 8 to 32 columns (the first layer of the VAE's encoder GRUs at hidden size 512,
+    reference VAE.py:119-120 -> 154-155, reads the table's features) is multiplied by W_ih inside the cluster form, from
+    the bf16 image of W_ih and the bias that tad_rnn_pack_input writes; no pre-activation tensor exists.  Outputs, stash
+    and the gradients that the backward makes of them against the oracle whose pre-activations skip the bf16 storage
+    rounding; h against the launch that reads stored pre-activations to the bf16 tolerance; the launch without a stash
+    gives the same h bit for bit."""
+    H = 512
+    rng = np.random.default_rng(777 + cell + B + IN)
+    r = _run_rnn(ops, dev, cell, 1, B, T, H, list(revs), rng, IN=IN, cluster=True, xin=True)
+    assert r["s16"] and r["fwd_kernel"].startswith("rnn_cluster_fwd_kernel") and r["fwd_kernel"].endswith("true>"), r["fwd_kernel"]
+    _check_rnn(r, cell, B, T, H, BF16_EMU_TOL)
+
+
+def test_rnn_fwd_ws_x_rejects_what_the_cluster_form_cannot_take(ops, dev):
+    """No silent other path: an input wider than 32 columns, a hidden size without the form, or no usable workspace is
+    an error that names the entry point."""
+    H, B, T = 512, 40, 2
+    ws = torch.zeros(ops.rnn_workspace_bytes(1, 1, 1, B, T, H, 1), dtype=torch.uint8, device=dev)
+    whh = torch.zeros(3 * H, H, device=dev)
+    pf = torch.empty(ops.rnn_packed_bytes(1, H, 3), dtype=torch.uint8, device=dev)
+    ops.rnn_pack_weights(1, H, 3, whh, pf, None)
+    out = torch.zeros(B * T, H, device=dev)
+    dirs = [dict(xproj=None, w_packed=pf, b_hh=torch.zeros(3 * H, device=dev), out=out, reverse=False)]
+
+    def xin(k):
+        return [dict(x16=torch.zeros(B * T, k, dtype=torch.bfloat16, device=dev), w_ih16=torch.zeros(4 * H, 128, dtype=torch.bfloat16, device=dev)[:, :k],
+                     bias=torch.zeros(4 * H, device=dev))]
+    ops.rnn_fwd(1, 1, B, T, H, dirs, workspace=ws, xin=xin(32))
+    with pytest.raises(ops._lib.TadError, match="tad_rnn_fwd_ws_x"):
+        ops.rnn_fwd(1, 1, B, T, H, dirs, workspace=ws, xin=xin(40))
+    with pytest.raises(ops._lib.TadError, match="tad_rnn_fwd_ws_x"):
+        ops.rnn_fwd(1, 1, B, T, H, dirs, workspace=torch.zeros(4096, dtype=torch.uint8, device=dev), xin=xin(32))
+    torch.cuda.synchronize()
 
 
 def _cluster_problem(ops, dev, cell, B, T, nd, seed):

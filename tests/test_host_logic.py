@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tad_abi_version() == 15
+    assert lib.tad_abi_version() == 16
     # bf16, H = 200, LSTM: the forward buffer holds the 32-row-form image (7 chunks x 13 k-blocks x 4 gates) and the
     # 16-row-form image (7 x 7 k-steps x 4 gates x 2 blocks of 16 units), the backward one 7 x 52 k-blocks; 1 KiB each
     assert lib.tad_rnn_packed_bytes(1, 200, 4) == max(7 * 13 * 4 + 7 * 7 * 4 * 2, 7 * (4 * 224 // 16)) * 1024

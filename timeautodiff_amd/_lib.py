@@ -25,6 +25,10 @@ class RnnDir(C.Structure):
                 ("out16", _p), ("ld_out16", _i64)]
 
 
+class RnnXin(C.Structure):
+    _fields_ = [("x16", _p), ("ldx", _i64), ("w_ih16", _p), ("ldw", _i64), ("bias", _p), ("kin", C.c_int32), ("pad_", C.c_int32)]
+
+
 class RnnBwdDir(C.Structure):
     _fields_ = [("dout", _p), ("ld_dout", _i64), ("gates", _p), ("ld_gates", _i64), ("cstate", _p), ("ld_c", _i64),
                 ("out", _p), ("ld_out", _i64), ("w_packed_t", _p), ("dgates", _p), ("ld_dgates", _i64),
@@ -67,6 +71,7 @@ PROTOTYPES = {
     "tad_rnn_fwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p]),
     "tad_rnn_workspace_bytes": (_i64, [_i, _i, _i, _i64, _i64, _i64, _i]),
     "tad_rnn_fwd_ws": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), _p, _i64, _p]),
+    "tad_rnn_fwd_ws_x": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnDir), C.POINTER(RnnXin), _p, _i64, _p]),
     "tad_rnn_ws_status": (_i, [_p, _p]),
     "tad_rnn_bwd": (_i, [_i, _i, _i, _i64, _i64, _i64, _i, C.POINTER(RnnBwdDir), _p]),
     "tad_rnn_pack_input": (_i, [_i, _i64, _i64, _i, _p, _p, _p, _p, _i, _i64, _p, _p]),

@@ -30,5 +30,5 @@ extern "C" const char* tad_last_kernel(void) {
   return g_kernel_out;
 }
 
-extern "C" int tad_abi_version(void) { return 15; }
+extern "C" int tad_abi_version(void) { return 16; }
 extern "C" const char* tad_last_error(void) { return g_err; }

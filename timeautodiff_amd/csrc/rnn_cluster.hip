@@ -70,6 +70,7 @@ static_assert(CL_LDS_BYTES <= 160 * 1024, "LDS");
 
 struct ClArgs {
   tad_rnn_dir_t d[2];          // w_packed: the cluster-form image
+  tad_rnn_xin_t xi[2];         // XIN launches: the layer's input and input-side weights instead of d[].xproj
   int B, T, ntiles, ndir, nslots, nitems;
   unsigned char* xbuf;
   unsigned* ctr;
@@ -99,7 +100,16 @@ __device__ __forceinline__ bool cl_wait(unsigned* ctr, unsigned target, unsigned
   }
 }
 
-template <int CELL, bool STASH>
+// XIN: the layer's input has at most 32 columns (the first layer of the VAE's encoders: the table's F features).  Its
+// input-side pre-activations are then not read from memory but formed here: x_t W_ih^T is one or two more MFMA steps on
+// the accumulators that W_hh h_{t-1} lands in, seeded with the bias (W_ih's slice: 8 registers).  The product that wrote
+// them ([B*T, 4H] bf16 per direction), its launch and a phase's 16 KB of loads through LDS are gone; the pre-activations
+// are no longer rounded to bf16 on the way.  GRU: the candidate gate's input side goes to the slot of the accumulator
+// that the recurrent image leaves empty (slot 3), its recurrent side stays in slot 2.
+constexpr int CL_LDXI = 40;            // row stride of the input tile in LDS (bf16; 32 columns + 8)
+constexpr size_t CL_XI_BIAS_OFF = 4096;                    // inside the first buffer of the pre-activation tiles (unused by XIN)
+
+template <int CELL, bool STASH, bool XIN>
 __global__ __launch_bounds__(512) void rnn_cluster_fwd_kernel(ClArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int dead;
@@ -132,6 +142,7 @@ __global__ __launch_bounds__(512) void rnn_cluster_fwd_kernel(ClArgs a) {
   unsigned long long acc_st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_st = __builtin_amdgcn_s_memtime();
 #endif
   uint4 wreg[CL_KS];
+  uint4 wih[XIN ? 2 : 1];
   int cur_dir = -1;
   unsigned gbase = 0;                                // steps every quarter of this group has published before the current item
 
@@ -142,6 +153,17 @@ __global__ __launch_bounds__(512) void rnn_cluster_fwd_kernel(ClArgs a) {
       const uint4* wp = reinterpret_cast<const uint4*>(d.w_packed) + (size_t)mw * CL_KS * 64 + lane;
 #pragma unroll
       for (int kk = 0; kk < CL_KS; ++kk) wreg[kk] = wp[kk * 64];
+      if constexpr (XIN) {
+        // A operand rows of the wave in the gate-interleaved image of W_ih (row 4 unit + slot; zeros beyond the input width)
+        const int m = lane & 31, slot = m & 3, unit = 8 * mw + 4 * ((m >> 2) & 1) + (m >> 3);
+        const int srow = (CELL == TAD_CELL_GRU && slot == 3) ? 2 : slot;
+        const bf16_t* wrow = reinterpret_cast<const bf16_t*>(a.xi[dir].w_ih16) + (int64_t)(4 * unit + srow) * a.xi[dir].ldw + 8 * hb;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          wih[kk] = *reinterpret_cast<const uint4*>(wrow + 16 * kk);
+          if (CELL == TAD_CELL_GRU && slot == 2) wih[kk] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
       cur_dir = dir;
     }
     const int64_t row0 = (int64_t)tile * CL_ROWS;
@@ -156,22 +178,33 @@ __global__ __launch_bounds__(512) void rnn_cluster_fwd_kernel(ClArgs a) {
 #define CL_VS (uint32_t)((sr * T * (int)d.ld_out16 + 64 * member + 8 * sc) * 2)
     // (the host admits only tensors of less than 2 GiB to this form: buffer addressing, 32-bit arithmetic throughout)
     auto rsrc_of = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000); };
-    const __amdgpu_buffer_rsrc_t x_rs = rsrc_of(d.xproj), g_rs = rsrc_of(d.gates), c_rs = rsrc_of(d.cstate), o_rs = rsrc_of(d.out), s_rs = rsrc_of(d.out16);
+    const __amdgpu_buffer_rsrc_t x_rs = rsrc_of(XIN ? a.xi[dir].x16 : d.xproj), g_rs = rsrc_of(d.gates), c_rs = rsrc_of(d.cstate), o_rs = rsrc_of(d.out), s_rs = rsrc_of(d.out16);
     auto row_off = [&](int q, int tt, int64_t ld, int esz, int extra_rows) -> uint32_t {     // byte offset of (row0 + 32 q + extra_rows, tt)
       return (uint32_t)((((int)row0 + CL_QR * q + extra_rows) * T + tt) * (int)ld * esz);
     };
-    // pre-activations of (quarter q, time tt): two 16-byte pieces per thread
+    // pre-activations of (quarter q, time tt): two 16-byte pieces per thread (XIN: the input rows, one piece for the first 128 threads)
+    const int xi_ld = XIN ? (int)a.xi[dir].ldx : 0, xi_nch = XIN ? a.xi[dir].kin >> 3 : 0;
     auto load_x = [&](int t2_, int q, int tt, u32x4_t* xv) {
       CL_COPY_IDX;
+      if constexpr (XIN) {
+        const int xr = t2_ >> 2, xc = t2_ & 3;           // row of the quarter, 16-byte piece of the row
+        const bool ok = t2_ < 128 && xc < xi_nch && CL_QR * q + xr < nrows;
+        xv[0] = __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? (uint32_t)((xr * T * xi_ld + 8 * xc) * 2) : CL_OOB, row_off(q, tt, xi_ld, 2, 0), 0);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)      // (no branch around a load: the wait for its result would drain every access in flight)
-        xv[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rs, CL_QR * q + gr + 16 * i < nrows ? CL_VX : CL_OOB, row_off(q, tt, d.ld_xproj, 2, 16 * i), 0);
+        for (int i = 0; i < 2; ++i)      // (no branch around a load: the wait for its result would drain every access in flight)
+          xv[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rs, CL_QR * q + gr + 16 * i < nrows ? CL_VX : CL_OOB, row_off(q, tt, d.ld_xproj, 2, 16 * i), 0);
+      }
     };
     auto put_x = [&](int t2_, int buf, const u32x4_t* xv) {
       CL_COPY_IDX;
+      if constexpr (XIN) {
+        if (t2_ < 128) *reinterpret_cast<u32x4_t*>(smem + CL_X_OFF + (size_t)buf * CL_X_BYTES + ((size_t)(t2_ >> 2) * CL_LDXI + 8 * (t2_ & 3)) * 2) = xv[0];
+      } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        *reinterpret_cast<u32x4_t*>(smem + CL_X_OFF + (size_t)buf * CL_X_BYTES + ((size_t)(gr + 16 * i) * CL_LDX + 8 * gc) * 2) = xv[i];
+        for (int i = 0; i < 2; ++i)
+          *reinterpret_cast<u32x4_t*>(smem + CL_X_OFF + (size_t)buf * CL_X_BYTES + ((size_t)(gr + 16 * i) * CL_LDX + 8 * gc) * 2) = xv[i];
+      }
     };
 
     for (int i = tid; i < (int)(2 * CL_T_BYTES / 16); i += 512) reinterpret_cast<uint4*>(smem + CL_T_OFF)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -183,6 +216,15 @@ __global__ __launch_bounds__(512) void rnn_cluster_fwd_kernel(ClArgs a) {
     float* const bhl = reinterpret_cast<float*>(smem + CL_BH_OFF);
     if constexpr (CELL == TAD_CELL_GRU) {
       if (tid < 192) bhl[tid] = d.b_hh ? d.b_hh[(tid >> 6) * CL_H + 64 * member + (tid & 63)] : 0.f;
+    }
+    if constexpr (XIN) {
+      // the bias of the workgroup's 256 gate rows in accumulator order (4 unit + slot), the GRU's candidate gate moved to slot 3.
+      // (Lives in the unused part of the first tile buffer: a tile is 32 x 40 bf16 here.)
+      if (tid < 256) {
+        const int slot = tid & 3, srow = (CELL == TAD_CELL_GRU && slot == 3) ? 2 : slot;
+        const float b = a.xi[dir].bias[4 * (64 * member + (tid >> 2)) + srow];
+        reinterpret_cast<float*>(smem + CL_X_OFF + CL_XI_BIAS_OFF)[tid] = (CELL == TAD_CELL_GRU && slot == 2) ? 0.f : b;
+      }
     }
     {
       u32x4_t xv[2];
@@ -263,6 +305,18 @@ __global__ __launch_bounds__(512) void rnn_cluster_fwd_kernel(ClArgs a) {
         // gates^T (32 gate rows of the wave x 32 batch rows) = x side + W_slice h_{t-1}^T
         f32x16 acc;
         float xn[4];
+        if constexpr (XIN) {
+          const f32x4* bl = reinterpret_cast<const f32x4*>(smem + CL_X_OFF + CL_XI_BIAS_OFF) + 8 * wave + 4 * hb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 b = bl[j];
+            acc[4 * j] = b[0]; acc[4 * j + 1] = b[1]; acc[4 * j + 2] = b[2]; acc[4 * j + 3] = b[3];
+            xn[j] = 0.f;
+          }
+          const unsigned char* xt = smem + CL_X_OFF + (size_t)(q & 1) * CL_X_BYTES + ((size_t)n * CL_LDXI + 8 * hb) * 2;
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wih[0]), *reinterpret_cast<const bf16x8*>(xt), acc, 0, 0, 0);
+          if (xi_nch > 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wih[1]), *reinterpret_cast<const bf16x8*>(xt + 32), acc, 0, 0, 0);
+        } else
         {
           const unsigned char* xp = xg_lane + CL_X_OFF + (size_t)(q & 1) * CL_X_BYTES;
           const u32x4_t x0 = *reinterpret_cast<const u32x4_t*>(xp), x1 = *reinterpret_cast<const u32x4_t*>(xp + 16);
@@ -316,7 +370,7 @@ __global__ __launch_bounds__(512) void rnn_cluster_fwd_kernel(ClArgs a) {
             } else {
               const float rg = fast_sigmoid(acc[4 * j] + bh[0][j]), zg = fast_sigmoid(acc[4 * j + 1] + bh[1][j]);
               const float hpn = acc[4 * j + 2] + bh[2][j];
-              const float ng = fast_tanh(xn[j] + rg * hpn);
+              const float ng = fast_tanh((XIN ? acc[4 * j + 3] : xn[j]) + rg * hpn);
               h = (1.f - zg) * ng + zg * st[q][j];
               st[q][j] = h;
               cv[j] = 0.f;
@@ -396,9 +450,9 @@ int cl_max_slots(const void* kernel) {
   return cached[dev] > 0 ? cached[dev] : 0;
 }
 
-template <int CELL, bool STASH>
+template <int CELL, bool STASH, bool XIN>
 int launch_cluster(ClArgs a, hipStream_t s) {
-  auto k = rnn_cluster_fwd_kernel<CELL, STASH>;
+  auto k = rnn_cluster_fwd_kernel<CELL, STASH, XIN>;
   static bool configured[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { tad_set_error("tad_rnn_fwd_ws: hipGetDevice failed"); return TAD_ERR_LAUNCH; }
@@ -414,7 +468,7 @@ int launch_cluster(ClArgs a, hipStream_t s) {
   if (e != hipSuccess) { tad_set_error("tad_rnn_fwd_ws: zeroing the counters failed: %s", hipGetErrorString(e)); return TAD_ERR_LAUNCH; }
   hipLaunchKernelGGL(k, dim3((unsigned)(a.nslots * CL_NC)), dim3(512), CL_LDS_BYTES, s, a);
   TAD_LAUNCH_CHECK();
-  tad_note_kernel("rnn_cluster_fwd_kernel<%d, %s>", CELL, STASH ? "true" : "false");
+  tad_note_kernel("rnn_cluster_fwd_kernel<%d, %s, %s>", CELL, STASH ? "true" : "false", XIN ? "true" : "false");
   return TAD_OK;
 }
 
@@ -428,8 +482,10 @@ extern "C" int64_t tad_rnn_workspace_bytes(int cell, int prec, int store, int64_
   return (int64_t)CL_WS_BYTES;
 }
 
-extern "C" int tad_rnn_fwd_ws(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
-                              void* workspace, int64_t workspace_bytes, tad_stream_t stream) {
+// xin == nullptr: the pre-activations come from dirs[].xproj; a call that the cluster form cannot take is tad_rnn_fwd.
+// xin != nullptr: the form multiplies the layer's narrow input itself; a call that it cannot take is an error.
+static int rnn_fwd_ws_any(const char* fn, int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
+                          const tad_rnn_xin_t* xin, void* workspace, int64_t workspace_bytes, tad_stream_t stream) {
   const int64_t need = tad_rnn_workspace_bytes(cell, prec, store, B, T, H, ndir);
   bool cluster = workspace && need > 0 && workspace_bytes >= need && (cell == TAD_CELL_LSTM || cell == TAD_CELL_GRU) &&
                  (ndir == 1 || ndir == 2) && dirs && T > 0 && al16(workspace);
@@ -439,7 +495,10 @@ extern "C" int tad_rnn_fwd_ws(int cell, int prec, int store, int64_t B, int64_t 
       const tad_rnn_dir_t& d = dirs[i];
       stash = stash || d.gates; all_stash = all_stash && d.gates;
       // every tensor moves in 16-byte pieces along its rows
-      cluster = cluster && d.xproj && d.w_packed && (d.out || d.out16) && al16(d.xproj) && d.ld_xproj % 8 == 0 && d.ld_xproj >= 4 * H &&
+      cluster = cluster && d.w_packed && (d.out || d.out16) &&
+                (xin ? (xin[i].x16 && al16(xin[i].x16) && xin[i].ldx % 8 == 0 && xin[i].kin >= 8 && xin[i].kin <= 32 && xin[i].kin % 8 == 0 &&
+                        xin[i].ldx >= xin[i].kin && xin[i].w_ih16 && al16(xin[i].w_ih16) && xin[i].ldw % 8 == 0 && xin[i].ldw >= 32 && xin[i].bias)
+                     : (d.xproj && al16(d.xproj) && d.ld_xproj % 8 == 0 && d.ld_xproj >= 4 * H)) &&
                 (!d.out || (al16(d.out) && d.ld_out % 4 == 0 && d.ld_out >= H)) &&
                 (!d.out16 || (al16(d.out16) && d.ld_out16 % 8 == 0 && d.ld_out16 >= H)) &&
                 (!d.gates || (al16(d.gates) && d.ld_gates % 8 == 0 && d.ld_gates >= 4 * H &&
@@ -448,18 +507,23 @@ extern "C" int tad_rnn_fwd_ws(int cell, int prec, int store, int64_t B, int64_t 
     // (the kernel's byte offsets are 32-bit)
     for (int i = 0; i < ndir && cluster; ++i) {
       const tad_rnn_dir_t& d = dirs[i];
-      const int64_t ldmax = std::max(std::max(d.ld_xproj, d.ld_gates), std::max(std::max(d.ld_out, d.ld_c) * 2, d.ld_out16));
+      const int64_t ldmax = std::max(std::max(xin ? xin[i].ldx : d.ld_xproj, d.ld_gates), std::max(std::max(d.ld_out, d.ld_c) * 2, d.ld_out16));
       cluster = (B + CL_ROWS) * T * ldmax * 2 < ((int64_t)1 << 31);
     }
     cluster = cluster && stash == all_stash;
   }
-  if (!cluster) return tad_rnn_fwd(cell, prec, store, B, T, H, ndir, dirs, stream);
+  if (!cluster) {
+    if (!xin) return tad_rnn_fwd(cell, prec, store, B, T, H, ndir, dirs, stream);
+    tad_set_error("%s: the cluster form does not take this call (shape, workspace, alignment or leading dimensions)", fn);
+    return TAD_ERR_INVALID;
+  }
 
   ClArgs a{};
   const int G = cell == TAD_CELL_LSTM ? 4 : 3;
   for (int i = 0; i < ndir; ++i) {
     a.d[i] = dirs[i];
     a.d[i].w_packed = reinterpret_cast<const unsigned char*>(dirs[i].w_packed) + rnn_fwd_image_blocks(prec, H, G) * 1024;
+    if (xin) a.xi[i] = xin[i];
   }
   a.B = (int)B; a.T = (int)T; a.ndir = ndir;
   a.ntiles = (int)cdiv64(B, CL_ROWS);
@@ -469,8 +533,23 @@ extern "C" int tad_rnn_fwd_ws(int cell, int prec, int store, int64_t B, int64_t 
   a.status = reinterpret_cast<unsigned*>(ws + CL_STATUS_OFF);
   a.xbuf = ws + CL_XBUF_OFF;
   hipStream_t s = (hipStream_t)stream;
-  if (cell == TAD_CELL_LSTM) return stash ? launch_cluster<TAD_CELL_LSTM, true>(a, s) : launch_cluster<TAD_CELL_LSTM, false>(a, s);
-  return stash ? launch_cluster<TAD_CELL_GRU, true>(a, s) : launch_cluster<TAD_CELL_GRU, false>(a, s);
+  if (xin) {
+    if (cell == TAD_CELL_LSTM) return stash ? launch_cluster<TAD_CELL_LSTM, true, true>(a, s) : launch_cluster<TAD_CELL_LSTM, false, true>(a, s);
+    return stash ? launch_cluster<TAD_CELL_GRU, true, true>(a, s) : launch_cluster<TAD_CELL_GRU, false, true>(a, s);
+  }
+  if (cell == TAD_CELL_LSTM) return stash ? launch_cluster<TAD_CELL_LSTM, true, false>(a, s) : launch_cluster<TAD_CELL_LSTM, false, false>(a, s);
+  return stash ? launch_cluster<TAD_CELL_GRU, true, false>(a, s) : launch_cluster<TAD_CELL_GRU, false, false>(a, s);
+}
+
+extern "C" int tad_rnn_fwd_ws(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
+                              void* workspace, int64_t workspace_bytes, tad_stream_t stream) {
+  return rnn_fwd_ws_any("tad_rnn_fwd_ws", cell, prec, store, B, T, H, ndir, dirs, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tad_rnn_fwd_ws_x(int cell, int prec, int store, int64_t B, int64_t T, int64_t H, int ndir, const tad_rnn_dir_t* dirs,
+                                const tad_rnn_xin_t* xin, void* workspace, int64_t workspace_bytes, tad_stream_t stream) {
+  TAD_CHECK(xin, "tad_rnn_fwd_ws_x: null xin");
+  return rnn_fwd_ws_any("tad_rnn_fwd_ws_x", cell, prec, store, B, T, H, ndir, dirs, xin, workspace, workspace_bytes, stream);
 }
 
 extern "C" int tad_rnn_ws_status(const void* workspace, tad_stream_t stream) {

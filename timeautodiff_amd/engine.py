@@ -28,6 +28,8 @@ SAMPLE_TAIL_NOISE = os.environ.get("TAD_SAMPLE_TAIL_NOISE", "1") != "0"
 MM16_MAX_4H = int(os.environ.get("TAD_MM16_MAX_4H", "4096"))
 # the VAE decoder's products on bf16-stored operands (bf16 mode)
 VAE_DEC16 = os.environ.get("TAD_VAE_DEC16", "1") != "0"
+# a first recurrent layer of at most 32 input columns at hidden size 512 (bf16 mode): x_t W_ih^T inside the sequence kernel
+RNN_XIN = os.environ.get("TAD_RNN_XIN", "1") != "0"
 # input-side products of a recurrent layer whose weight has at least this many elements take the square-tiled kernel
 XPROJ_TILED_MIN = int(os.environ.get("TAD_XPROJ_TILED_MIN", str(1 << 21)))
 # TAD_SAMPLE_GRAPH=1: replay the reverse loop as one captured HIP graph per batch shape instead of enqueueing it kernel
@@ -506,9 +508,25 @@ class RnnStack:
         for layer in range(self.L):
             sdt = self.store[layer]
             last = layer == self.L - 1
-            xproj = ws.get(f"{tag}.xproj{layer}", (BT, nd * H4), dtype=sdt)
+            # H = 512 in bf16: the form that keeps W_hh on chip, split over eight workgroups that exchange h_t through
+            # device memory (one buffer per stack and workspace: the launches of a stream follow each other)
+            wsb = ops.rnn_workspace_bytes(self.cell, prec, BF16 if sdt == torch.bfloat16 else F32, B, T, H, nd)
+            # ... and a first layer that reads few columns (the VAE's encoders: the table's features) multiplies them by
+            # W_ih inside that form: no pre-activation tensor [B*T, ndir*4H] is written or read
+            fused = None
+            if RNN_XIN and layer == 0 and wsb > 0 and self.mm16[0] and self.in_p(0) <= 32:
+                x16 = x if x.dtype == torch.bfloat16 else self._in16
+                if x16 is None:
+                    x16 = ws.get(f"{tag}.in16", (BT, self.in_p(0)), dtype=torch.bfloat16, zero="new")
+                    ops.cvt_bf16(x, x16[:, :self.in_l(0)])
+                if x16.shape[1] == self.in_p(0):
+                    fused = [dict(x16=x16, w_ih16=self.w_gl[0][d * H4:(d + 1) * H4], bias=self.bias_gl[0][d * H4:(d + 1) * H4])
+                             for d in range(nd)]
+            xproj = ws.get(f"{tag}.xproj{layer}", (BT, nd * H4), dtype=sdt) if fused is None else None
             w = self.w_img[layer] if self.mm16[layer] else self.w_gl[layer]
-            if self.mode == "bidir" or layer == 0:
+            if fused is not None:
+                pass
+            elif self.mode == "bidir" or layer == 0:
                 xin = inp if inp.dtype == torch.bfloat16 else self._padded(layer, inp, ws, tag)
                 self._xproj(layer, xin, w, self.bias_gl[layer], xproj)
             else:
@@ -533,17 +551,14 @@ class RnnStack:
             for d in range(nd):
                 sl = slice(d * H4, (d + 1) * H4)
                 hs = slice(d * H, (d + 1) * H)
-                dirs.append(dict(xproj=xproj[:, sl], w_packed=self.packed_f[layer][d],
+                dirs.append(dict(xproj=xproj[:, sl] if xproj is not None else None, w_packed=self.packed_f[layer][d],
                                  b_hh=fp.p(self.name("bias_hh", layer, d)) if not lstm else None,
                                  out=out[:, hs] if out is not None else None,
                                  out16=out16[:, hs] if out16 is not None else None, gates=gates[:, sl] if train else None,
                                  cstate=cst[:, hs] if cst is not None else None, reverse=self.rev[d]))
             fp.release()
-            # H = 512 in bf16: the form that keeps W_hh on chip, split over eight workgroups that exchange h_t through
-            # device memory (one buffer per stack and workspace: the launches of a stream follow each other)
-            wsb = ops.rnn_workspace_bytes(self.cell, prec, BF16 if sdt == torch.bfloat16 else F32, B, T, H, nd)
             cl_ws = ws.get(f"{tag}.rnn_ws", (wsb,), dtype=torch.uint8, zero="new") if wsb > 0 else None
-            ops.rnn_fwd(self.cell, prec, B, T, H, dirs, workspace=cl_ws)
+            ops.rnn_fwd(self.cell, prec, B, T, H, dirs, workspace=cl_ws, xin=fused)
             inp = out16 if (not last and self.mm16[layer + 1] and out16 is not None) else out
         return inp
 

@@ -12,7 +12,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ACT_DSILU, ACT_SILU_Z32, BF16, CELL_GRU, CELL_LSTM, F32, RnnBwdDir, RnnDir  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ACT_DSILU, ACT_SILU_Z32, BF16, CELL_GRU, CELL_LSTM, F32, RnnBwdDir, RnnDir, RnnXin  # noqa: F401
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -509,16 +509,30 @@ def check_rnn_workspaces(device=None):
             rnn_ws_status(w)
 
 
-def rnn_fwd(cell, prec, B, T, H, dirs, workspace=None):
+def rnn_fwd(cell, prec, B, T, H, dirs, workspace=None, xin=None):
     """dirs: list of dict(xproj (2-d view, float32 or bfloat16, gate-interleaved), w_packed, b_hh, out,
     gates (same dtype as xproj, or None = inference), cstate (LSTM training), reverse).  workspace: a zero-initialised
-    uint8 tensor of rnn_workspace_bytes(...) bytes that no other launch in flight uses, or None."""
+    uint8 tensor of rnn_workspace_bytes(...) bytes that no other launch in flight uses, or None.
+    xin (needs a workspace; bfloat16 storage): per direction dict(x16 [B*T, kin] bfloat16 with kin in (8, 16, 24, 32),
+    w_ih16 = the direction's rows of rnn_pack_input's bfloat16 image (row stride >= 32, zeros beyond kin), bias = its rows
+    of bias_gl): the sequence kernel forms the input-side pre-activations itself and the dirs carry no xproj."""
     arr = (RnnDir * len(dirs))()
-    store = _store_of(dirs[0]["xproj"])
+    xarr = None
+    if xin is not None:
+        assert workspace is not None and len(xin) == len(dirs)
+        xarr = (RnnXin * len(dirs))()
+        for k, xi in enumerate(xin):
+            x16, _, kin, ldx = as2d(xi["x16"], torch.bfloat16)
+            w16, _, kw, ldw = as2d(xi["w_ih16"], torch.bfloat16)
+            assert kw >= kin and xi["bias"].dtype == torch.float32 and xi["bias"].is_contiguous() and xi["bias"].numel() == 4 * H
+            xarr[k] = RnnXin(x16, ldx, w16, ldw, xi["bias"].data_ptr(), kin, 0)
+    store = BF16 if xin is not None else _store_of(dirs[0]["xproj"])
     for k, d in enumerate(dirs):
-        dt = d["xproj"].dtype
-        assert _store_of(d["xproj"]) == store
-        xp, _, _, ldxp = as2d(d["xproj"], dt)
+        dt = torch.bfloat16 if xin is not None else d["xproj"].dtype
+        xp, ldxp = None, 0
+        if xin is None:
+            assert _store_of(d["xproj"]) == store
+            xp, _, _, ldxp = as2d(d["xproj"], dt)
         op, ldo, o16, ldo16 = None, 0, None, 0
         if d.get("out") is not None:
             op, _, _, ldo = as2d(d["out"])
@@ -532,12 +546,18 @@ def rnn_fwd(cell, prec, B, T, H, dirs, workspace=None):
                 cp, _, _, ldc = as2d(d["cstate"])
         arr[k] = RnnDir(xp, ldxp, d["w_packed"].data_ptr(), _ptr(d.get("b_hh")), op, ldo, gp, ldg, cp, ldc,
                         int(d["reverse"]), 0, o16, ldo16)
-    G, nd, esz = (4 if cell == CELL_LSTM else 3), len(dirs), dirs[0]["xproj"].element_size()
+    G, nd, esz = (4 if cell == CELL_LSTM else 3), len(dirs), (2 if xin is not None else dirs[0]["xproj"].element_size())
     train = dirs[0].get("gates") is not None
     h_bytes = (4 if dirs[0].get("out") is not None else 0) + (2 if dirs[0].get("out16") is not None else 0)
-    per_elem = 4 * esz + h_bytes + ((4 * esz + (4 if cell == CELL_LSTM else 0)) if train else 0)     # xproj in, h out, stash out
+    per_elem = (0 if xin is not None else 4 * esz) + h_bytes + ((4 * esz + (4 if cell == CELL_LSTM else 0)) if train else 0)     # xproj in, h out, stash out
     cost = (2.0 * B * T * nd * G * H * H, float(B * T * nd * H * per_elem))
-    if workspace is not None:
+    if xin is not None:
+        kin = int(xarr[0].kin)
+        cost = (cost[0] + 2.0 * B * T * nd * G * H * kin, cost[1] + float(B * T * nd * kin * 2))
+        assert workspace.dtype == torch.uint8 and workspace.is_contiguous()
+        _RNN_WS[id(workspace)] = weakref.ref(workspace)
+        _call("tad_rnn_fwd_ws_x", cell, prec, store, B, T, H, nd, arr, xarr, workspace.data_ptr(), workspace.numel(), _stream(), cost=cost)
+    elif workspace is not None:
         assert workspace.dtype == torch.uint8 and workspace.is_contiguous()
         _RNN_WS[id(workspace)] = weakref.ref(workspace)
         _call("tad_rnn_fwd_ws", cell, prec, store, B, T, H, nd, arr, workspace.data_ptr(), workspace.numel(), _stream(), cost=cost)
