@@ -1418,8 +1418,8 @@ class VAEEngine:
         self.emb_dec.use_mm16(self.imgs)
         self.im = {}
         if MM16 and self.prec == BF16 and self.H % 8 == 0 and all(self.enc.mm16):
-            self.im = dict(fc_mu=self.imgs.add(self.fp.p("fc_mu.weight"), fwd=False, tr=True),
-                           fc_logvar=self.imgs.add(self.fp.p("fc_logvar.weight"), fwd=False, tr=True))
+            self.im = dict(fc_mu=self.imgs.add(self.fp.p("fc_mu.weight"), fwd=True, tr=True),
+                           fc_logvar=self.imgs.add(self.fp.p("fc_logvar.weight"), fwd=True, tr=True))
             if VAE_DEC16:
                 # the decoder's three products (reference VAE.py:200-219) on bf16-stored operands as well: z padded to 8 columns,
                 # the fused head outputs to a multiple of 8 (the spare columns meet zero weights and are never read)
@@ -1441,8 +1441,16 @@ class VAEEngine:
         hh = self.enc.forward(e, B, T, ws, tag, train)
         mu = ws.get("mu", (BT, Lt))
         lv = ws.get("lv", (BT, Lt))
-        ops.linear_fwd(prec, hh[:, :H], fp.p("fc_mu.weight"), fp.p("fc_mu.bias"), mu)
-        ops.linear_fwd(prec, hh[:, H:], fp.p("fc_logvar.weight"), fp.p("fc_logvar.bias"), lv)
+        h16 = self.enc.out16[-1]
+        if "fc_mu" in self.im and h16 is not None:
+            # the bf16 copy of h that the sequence kernel wrote for the weight gradients holds the operand values of the
+            # bf16 mode: half the bytes of the fp32 rows
+            self.imgs.pack()
+            ops.linear_fwd_b16x(h16[:, :H], self.im["fc_mu"]["fwd"][:Lt, :H], fp.p("fc_mu.bias"), mu)
+            ops.linear_fwd_b16x(h16[:, H:], self.im["fc_logvar"]["fwd"][:Lt, :H], fp.p("fc_logvar.bias"), lv)
+        else:
+            ops.linear_fwd(prec, hh[:, :H], fp.p("fc_mu.weight"), fp.p("fc_mu.bias"), mu)
+            ops.linear_fwd(prec, hh[:, H:], fp.p("fc_logvar.weight"), fp.p("fc_logvar.bias"), lv)
         z = ws.get("z", (BT, Lt))
         eps2 = eps.reshape(BT, Lt)
         ops.vae_reparam_fwd(mu, lv, eps2, z, kld_sum)
