@@ -462,12 +462,20 @@ def test_rnn_fwd_ws_x_rejects_what_the_cluster_form_cannot_take(ops, dev):
     torch.cuda.synchronize()
 
 
-def _cluster_problem(ops, dev, cell, B, T, nd, seed):
-    """Random operands of one forward launch at H = 512 in bf16 storage, and a function that runs it into fresh outputs."""
+def _cluster_problem(ops, dev, cell, B, T, nd, seed, xin=False):
+    """Random operands of one forward launch at H = 512 in bf16 storage, and a function that runs it into fresh outputs.
+    xin: the launch multiplies a 16-column input by W_ih itself instead of reading pre-activations."""
     H, G = 512, (4 if cell == 0 else 3)
     g = torch.Generator(device="cpu").manual_seed(seed)
     BT, H4 = B * T, 4 * H
     xproj = (torch.randn(BT, nd * H4, generator=g) * 0.7).to(dev).to(torch.bfloat16)
+    xi = None
+    if xin:
+        x16 = torch.randn(BT, 16, generator=g).to(dev).to(torch.bfloat16)
+        w16 = torch.zeros(nd * H4, 128, dtype=torch.bfloat16, device=dev)
+        w16[:, :16] = (torch.randn(nd * H4, 16, generator=g) * 0.2).to(dev).to(torch.bfloat16)
+        bias = (torch.randn(nd * H4, generator=g) * 0.1).to(dev)
+        xi = [dict(x16=x16, w_ih16=w16[d * H4:(d + 1) * H4, :16], bias=bias[d * H4:(d + 1) * H4]) for d in range(nd)]
     whh = ((torch.rand(nd, G * H, H, generator=g) * 2 - 1) / H ** 0.5).to(dev)
     bhh = ((torch.rand(nd, G * H, generator=g) * 2 - 1) / H ** 0.5).to(dev)
     nbytes = ops.rnn_packed_bytes(1, H, G)
@@ -480,35 +488,38 @@ def _cluster_problem(ops, dev, cell, B, T, nd, seed):
         out16 = torch.zeros(BT, nd * H, dtype=torch.bfloat16, device=dev)
         gates = torch.zeros(BT, nd * H4, dtype=torch.bfloat16, device=dev)
         cst = torch.zeros(BT, nd * H, device=dev)
-        dirs = [dict(xproj=xproj[:, d * H4:(d + 1) * H4], w_packed=pf[d], b_hh=bhh[d] if cell == 1 else None,
+        dirs = [dict(xproj=None if xin else xproj[:, d * H4:(d + 1) * H4], w_packed=pf[d], b_hh=bhh[d] if cell == 1 else None,
                      out=out[:, d * H:(d + 1) * H], out16=out16[:, d * H:(d + 1) * H],
                      gates=gates[:, d * H4:(d + 1) * H4] if stash else None,
                      cstate=cst[:, d * H:(d + 1) * H] if (stash and cell == 0) else None, reverse=bool(d & 1)) for d in range(nd)]
-        ops.rnn_fwd(cell, 1, B, T, H, dirs, workspace=workspace)
+        ops.rnn_fwd(cell, 1, B, T, H, dirs, workspace=workspace, xin=xi)
         return out, out16, gates, cst
     return run
 
 
+@pytest.mark.parametrize("xin", [False, True])
 @pytest.mark.parametrize("cell", [0, 1])
-def test_rnn_cluster_form_beside_other_work_and_replayed(ops, dev, cell):
+def test_rnn_cluster_form_beside_other_work_and_replayed(ops, dev, cell, xin):
     """The eight workgroups of a group hand h_t to each other through device memory every step.  The launch must give the
     same bits (a) alone on the chip, (b) while another stream keeps the chip busy with memory-bound kernels, so that the
     workgroups of a group start at different times and meet loaded memory paths, (c) many times in a row on one workspace
     (arrival counters are re-zeroed by every launch; the consumers' caches have seen the exchange buffers before), and
     (d) replayed from a captured HIP graph (the memset of the counters is a node of the graph).  Against the forms that
-    need no workspace: to the tolerance of the bf16 mode (another summation order)."""
+    need no workspace: to the tolerance of the bf16 mode (another summation order).  xin: the same for the launch that
+    multiplies a narrow layer input itself (tad_rnn_fwd_ws_x; it has no form without a workspace to compare with)."""
     B, T, nd = 700, 7, 2
-    run = _cluster_problem(ops, dev, cell, B, T, nd, 77 + cell)
+    run = _cluster_problem(ops, dev, cell, B, T, nd, 77 + cell, xin=xin)
     nws = ops.rnn_workspace_bytes(cell, 1, 1, B, T, 512, nd)
     assert nws > 0
     ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
     ref = run(ws)
     assert ops._lib.load().tad_last_kernel().decode().startswith("rnn_cluster_fwd_kernel")
     ops.rnn_ws_status(ws)
-    plain = run(None)
-    assert not ops._lib.load().tad_last_kernel().decode().startswith("rnn_cluster_fwd_kernel")
-    for a, b in zip(ref, plain):
-        assert fu.rel_err(a.float().cpu().numpy(), b.float().cpu().numpy()) < BF16_EMU_TOL
+    if not xin:
+        plain = run(None)
+        assert not ops._lib.load().tad_last_kernel().decode().startswith("rnn_cluster_fwd_kernel")
+        for a, b in zip(ref, plain):
+            assert fu.rel_err(a.float().cpu().numpy(), b.float().cpu().numpy()) < BF16_EMU_TOL
     # (b) + (c): a side stream streams 256 MB copies all the while
     side = torch.cuda.Stream()
     big = torch.empty(64 << 20, device=dev)
