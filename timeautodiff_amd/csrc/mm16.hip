@@ -445,6 +445,14 @@ extern "C" int tad_dbg_mm16_stamps(unsigned long long* out8, int reset) {
 namespace {
 #endif
 
+// Measured at 98 304 rows: one item per panel beats two for N = 128 (14.4 vs 17.4 us) and N = 400, K = 200 (35.9 vs 41.6 us),
+// equals it at N = K = 432, loses from N = 1600 on: an item costs about two chunk-times before its first chunk.
+inline double nt_item_overhead() {
+  static const char* e = getenv("TAD_MM16_NT_OVERHEAD");
+  static const double v = e ? atof(e) : 2.0;
+  return v;
+}
+
 template <int KS16>
 int launch_nt(NtParams& p, hipStream_t s) {
   constexpr int NW = NT_NW, BM = 32 * NW;
@@ -458,7 +466,7 @@ int launch_nt(NtParams& p, hipStream_t s) {
     const int cps = (p.nchunks + ns - 1) / ns;
     const int64_t items = panels * ns;
     const double rounds = (double)cdiv64(items, slots);
-    const double cost = rounds * (cps + 0.7);            // 0.7 chunk-times: loading the A panel and the pipeline fill
+    const double cost = rounds * (cps + nt_item_overhead());     // chunk-times of an item before its first chunk: loading the A panel, the pipeline fill
     if (cost < best_cost - 1e-9) { best_cost = cost; best = ns; }
   }
   static const char* force = getenv("TAD_MM16_NSPLIT");
