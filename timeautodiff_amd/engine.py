@@ -571,7 +571,9 @@ class RnnStack:
         if self.mm16[layer] and self.out16[layer] is not None:
             # one launch: the input-side and both recurrent products read the pre-activation gradients once
             jobs = []
-            if inp.dtype == torch.bfloat16 and inp.shape[1] == (self.in_l(layer) if shared else nd * H):
+            if inp.dtype == torch.bfloat16 and (inp.shape[1] == (self.in_l(layer) if shared else nd * H) or
+                                                (shared and inp.shape[1] == self.in_p(layer))):
+                # (a zero-padded input: the product's spare columns are dropped, the gradient is in_l wide)
                 if shared:
                     jobs.append(dict(b=inp, c=fp.ggroup(self.name("weight_ih", layer, 0), nd * GH, self.in_l(layer)), a0=0,
                                      na=nd * H4, gate_map=in_map, db=gb_ih, db2=gb_hh if lstm else None))
@@ -658,7 +660,9 @@ class RnnStack:
             if layer > 0 or need_dx:
                 padded = shared and self.in_p(layer) != in_l
                 wl = self.w_gl[layer][:, :self.in_p(layer)]
-                if layer == 0 and dx16 is not None and sdt == torch.bfloat16 and shared and not padded:
+                if layer == 0 and dx16 is not None and sdt == torch.bfloat16 and shared and (not padded or
+                                                                                             (dx16.shape[1] == self.in_p(0) and relu_of is None)):
+                    # (a padded gradient: its spare columns meet the image's zero columns and hold zeros)
                     ops.linear_bwd_data_b16o(dg, wl, dx16, relu_of16=relu_of, useful=G / 4.0)
                     dout = dx16
                     continue
@@ -697,7 +701,7 @@ class EmbBlock:
         for c in self.cards[:-1]:
             self.tab_off.append(self.tab_off[-1] + c)
         self.cat_dim = self.nd * E + 16 * n_nums
-        self.mm16 = False
+        self.mm16 = self.last16 = self.pad16 = False
 
     @staticmethod
     def layout(prefix, n_disc, n_nums):
@@ -709,21 +713,29 @@ class EmbBlock:
                 (f"{prefix}mlp_output.2.weight", False), (f"{prefix}mlp_output.2.bias", False)]
         return out
 
-    def use_mm16(self, imgs):
+    def use_mm16(self, imgs, pad_last=False):
         """Switch the block to the bf16-stored-operand products (bf16 precision, widths that are multiples of 8):
-        registers its weight images with ``imgs`` (W16Images).  The last layer joins when its width allows."""
+        registers its weight images with ``imgs`` (W16Images).  The last layer joins when its width allows, or, with
+        ``pad_last``, on a result padded to a multiple of 8 columns (the spare columns meet zero weights and a zero bias:
+        they hold zeros; forward(want16=True) then returns the padded bfloat16 result and backward takes a gradient of
+        that width)."""
         fp, pre = self.fp, self.prefix
         if not (MM16 and self.prec == BF16 and self.E % 8 == 0):
             return
         self.imgs = imgs
-        self.last16 = fp.p(pre + "mlp_output.2.weight").shape[0] % 8 == 0
+        self.out_w = fp.p(pre + "mlp_output.2.weight").shape[0]
+        self.out_p = -(-self.out_w // 8) * 8
+        self.last16 = self.out_w % 8 == 0
+        self.pad16 = bool(pad_last) and not self.last16
         self.im = {}
         if self.nn:
             self.im["n0"] = imgs.add(fp.p(pre + "mlp_nums.0.weight"), fwd=True, tr=False)
             self.im["n2"] = imgs.add(fp.p(pre + "mlp_nums.2.weight"), fwd=True, tr=True)
         self.im["o0"] = imgs.add(fp.p(pre + "mlp_output.0.weight"), fwd=True, tr=True)
-        if self.last16:
+        if self.last16 or self.pad16:
             self.im["o2"] = imgs.add(fp.p(pre + "mlp_output.2.weight"), fwd=True, tr=True)
+        if self.pad16:
+            self.im["o2_bias"] = imgs.add_padded_bias(fp.p(pre + "mlp_output.2.bias"), self.out_p)
         self.mm16 = True
 
     def forward(self, x, ws: Workspace, tag, want16=False):
@@ -774,7 +786,13 @@ class EmbBlock:
             ops.mm16_nt(feats, im["n0"]["fwd"], fp.p(pre + "mlp_nums.0.bias"), a1, act=ACT_SILU_Z32, z_out=z1)
             ops.mm16_nt(a1, im["n2"]["fwd"], fp.p(pre + "mlp_nums.2.bias"), ecat[:, nd * E:])
         w2 = fp.p(pre + "mlp_output.2.weight")
-        if self.last16:
+        if self.pad16:
+            a2 = ws.get(f"{tag}.a2_16", (rows, E), dtype=b16)
+            ops.mm16_nt(ecat, im["o0"]["fwd"], fp.p(pre + "mlp_output.0.bias"), a2, act=ACT_RELU)
+            outp = ws.get(f"{tag}.out16p" if want16 else f"{tag}.outp", (rows, self.out_p), dtype=b16 if want16 else torch.float32)
+            ops.mm16_nt(a2, im["o2"]["fwd"], im["o2_bias"], outp)
+            out = outp if want16 else outp[:, :self.out_w]
+        elif self.last16:
             a2 = ws.get(f"{tag}.a2_16", (rows, E), dtype=b16)
             ops.mm16_nt(ecat, im["o0"]["fwd"], fp.p(pre + "mlp_output.0.bias"), a2, act=ACT_RELU)
             out = ws.get(f"{tag}.out16" if want16 else f"{tag}.out", (rows, w2.shape[0]), dtype=b16 if want16 else torch.float32)
@@ -824,14 +842,16 @@ class EmbBlock:
         ecat = ws.get(f"{tag}.ecat16", (rows, self.cat_dim), dtype=b16)
         da2 = ws.get(f"{tag}.da2_16", (rows, E), dtype=b16)
         gw2, gb2 = fp.g(pre + "mlp_output.2.weight"), fp.g(pre + "mlp_output.2.bias")
-        if self.last16:
+        if self.last16 or self.pad16:
             a2 = ws.get(f"{tag}.a2_16", (rows, E), dtype=b16)
             if dout.dtype != b16:
-                d16 = ws.get(f"{tag}.dout16", tuple(dout.shape), dtype=b16)
-                ops.cvt_bf16(dout, d16)
+                # (padded result: the gradient's spare columns are zeros, written once)
+                d16 = ws.get(f"{tag}.dout16", (rows, self.out_p), dtype=b16, zero="new")
+                ops.cvt_bf16(dout, d16[:, :dout.shape[1]])
                 dout = d16
+            assert dout.shape[1] == self.out_p
             ops.mm16_nt(dout, im["o2"]["tr"], None, da2, relu_of=a2)
-            fp.queue_tn(dout, dict(b=a2, c=gw2, db=gb2))
+            fp.queue_tn(dout, dict(b=a2, c=gw2, db=gb2, a0=0, na=self.out_w))
         else:
             a2 = ws.get(f"{tag}.a2", (rows, E))
             da2f = ws.get(f"{tag}.da2", (rows, E))
@@ -1414,7 +1434,8 @@ class VAEEngine:
         self.emb_dec = EmbBlock(self.fp, "Emb_decoder.", nb, nc, nn, self.cards, self.E, self.prec)
         # bf16 mode: the embedding blocks and the two latent projections' backward take the bf16-stored-operand products
         self.imgs = W16Images(self.fp)
-        self.emb.use_mm16(self.imgs)
+        # (the encoder's embedding block hands its result to the GRUs as bfloat16, padded to a multiple of 8 columns)
+        self.emb.use_mm16(self.imgs, pad_last=all(self.enc.mm16))
         self.emb_dec.use_mm16(self.imgs)
         self.im = {}
         if MM16 and self.prec == BF16 and self.H % 8 == 0 and all(self.enc.mm16):
@@ -1436,7 +1457,8 @@ class VAEEngine:
         BT = B * T
         fp.defer(self.enc.pack if train else self.enc.pack_fwd_only)       # beside the embedding block
         x2 = inp.reshape(BT, self.F)
-        e = self.emb.forward(x2, ws, "emb")
+        self._e16 = bool(self.emb.mm16 and (self.emb.last16 or self.emb.pad16) and self.enc.mm16[0])
+        e = self.emb.forward(x2, ws, "emb", want16=self._e16)
         fp.join()
         hh = self.enc.forward(e, B, T, ws, tag, train)
         mu = ws.get("mu", (BT, Lt))
@@ -1622,6 +1644,8 @@ class VAEEngine:
         else:
             _lin_bwd(fp, prec, dmu, hh[:, :H], fp.p("fc_mu.weight"), fp.g("fc_mu.weight"), fp.g("fc_mu.bias"), dx=dhh[:, :H])
             _lin_bwd(fp, prec, dlv, hh[:, H:], fp.p("fc_logvar.weight"), fp.g("fc_logvar.weight"), fp.g("fc_logvar.bias"), dx=dhh[:, H:])
-        de = self.enc.backward(dhh, ws, "enc", need_dx=True)
+        # (the gradient of the embedding block's bfloat16 result leaves the input-gradient product as bfloat16)
+        dx16 = ws.get("enc.dx16", (BT, self.enc.in_p(0)), dtype=torch.bfloat16) if self._e16 else None
+        de = self.enc.backward(dhh, ws, "enc", need_dx=True, dx16=dx16)
         self.emb.backward(de, ws, "emb")
         fp.join()
