@@ -314,6 +314,12 @@ def w16_image(n, k, device):
 
 LN_FC_MAX_D = int(os.environ.get("TAD_LN_FC_MAX_D", "1024"))     # widest row of the fused LayerNorm + fc launches (experiments: 512)
 MM16_NT_MAX_K = 1024        # tad_mm16_nt keeps a wave's 32 rows of A in registers: K at most 1024
+# plain products (bias, ReLU) that leave tad_mm16_nt for the square-tiled kernel: K from NT_TILED_K on, or from
+# NT_TILED_K_NARROW on with at most NT_TILED_N_NARROW result columns (TAD_NT_TILED=0: none)
+NT_TILED = os.environ.get("TAD_NT_TILED", "1") != "0"
+NT_TILED_K = int(os.environ.get("TAD_NT_TILED_K", "768"))
+NT_TILED_K_NARROW = int(os.environ.get("TAD_NT_TILED_K_NARROW", "384"))
+NT_TILED_N_NARROW = int(os.environ.get("TAD_NT_TILED_N_NARROW", "512"))
 
 
 def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=None, useful=1.0):
@@ -325,10 +331,17 @@ def mm16_nt(a16, w16, bias, c, act=ACT_NONE, residual=None, relu_of=None, z_out=
     cp, Mc, N, ldc = as2d(c, c.dtype)
     wp, Nw, Kw, ldw = as2d(w16, torch.bfloat16)
     assert M == Mc and Nw >= -(-N // 64) * 64 and Kw >= -(-K // 128) * 128 and Kw - K < 128, (a16.shape, w16.shape, c.shape)
+    plain = residual is None and relu_of is None and z_out is None and act in (ACT_NONE, ACT_RELU)
     if K > MM16_NT_MAX_K:
         # more of A than a wave keeps in registers (proj and cond_output + input_proj at hidden size 512): the square-tiled
         # kernel on the same operands, for the plain epilogues it has
-        assert residual is None and relu_of is None and z_out is None and act in (ACT_NONE, ACT_RELU), "mm16_nt: K > 1024 with a fused operand"
+        assert plain, "mm16_nt: K > 1024 with a fused operand"
+        return linear_fwd_b16x(a16, w16[:N, :K], bias, c, act=act, useful=useful)
+    if plain and NT_TILED and (K >= NT_TILED_K or (K >= NT_TILED_K_NARROW and N <= NT_TILED_N_NARROW)):
+        # long reductions: tad_mm16_nt holds 32 rows x K of A per wave in registers, so from K = 592 on a CU runs four waves
+        # and the loads of A, the ring and the stores follow each other; the square-tiled kernel measured 15-45 % faster
+        # for K >= 800 at every N and 3-30 % for K = 400-512 up to N = 512 (98 304 rows; scripts/nt_vs_tiled_k.py).  The
+        # choice depends on N and K only: a batch split differently meets the same kernels.
         return linear_fwd_b16x(a16, w16[:N, :K], bias, c, act=act, useful=useful)
     rp = ldr = up = ldu = zp = ldz = 0
     rdt = udt = F32
