@@ -84,6 +84,35 @@ def test_mm16_nt_fused_epilogues(ops, dev, M, N, K):
     _nt(ops, dev, M, N, K, False, act=3, relu="f32", bias=False)
 
 
+@pytest.mark.parametrize("M,N,K,tiled", [(300, 200, 800, True), (300, 128, 560, True), (300, 512, 512, True), (300, 1600, 400, False),
+                                          (300, 200, 200, False), (300, 800, 512, False), (300, 1600, 800, True)])
+def test_mm16_nt_plain_products_with_long_reductions_take_the_tiled_kernel(ops, dev, monkeypatch, M, N, K, tiled):
+    """ops.mm16_nt hands products with a plain epilogue to the square-tiled kernel from K = 768 on, and from K = 384 on
+    up to 512 result columns (a choice by N and K alone: the same kernel serves every row count); any fused operand
+    keeps tad_mm16_nt's own kernel.  Both kernels against the float64 product, and against each other to bf16 rounding."""
+    last = lambda: ops._lib.load().tad_last_kernel().decode()      # noqa: E731
+    g = torch.Generator(device=dev).manual_seed(N + K)
+    A = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    Wp = ops.w16_image(N, K, dev)
+    Wp[:N, :K] = (torch.randn(N, K, device=dev, generator=g) * 0.1).bfloat16()
+    b = torch.randn(N, device=dev, generator=g)
+    ref = (A.double() @ Wp[:N, :K].double().T + b.double()).clamp_min(0)
+    C1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.mm16_nt(A, Wp, b, C1, act=1)
+    assert last().startswith("gemm_kernel" if tiled else "mm16_nt_kernel"), last()
+    monkeypatch.setattr(ops, "NT_TILED", False)
+    C2 = torch.empty_like(C1)
+    ops.mm16_nt(A, Wp, b, C2, act=1)
+    assert last().startswith("mm16_nt_kernel"), last()
+    monkeypatch.setattr(ops, "NT_TILED", True)
+    R = torch.randn(M, N, device=dev, generator=g)
+    C3 = torch.empty_like(C1)
+    ops.mm16_nt(A, Wp, b, C3, act=1, residual=R)
+    assert last().startswith("mm16_nt_kernel"), last()
+    torch.cuda.synchronize()
+    assert _rel(C1, ref) < 4e-3 and _rel(C2, ref) < 4e-3 and _rel(C1, C2) < 4e-3
+
+
 def test_mm16_nt_dsilu_equals_product_then_silu_bwd(ops, dev):
     """act = DSILU against the two launches it replaces (product into float32, then tad_silu_bwd): the same values up to
     the sigmoid's last bits (hardware exp / reciprocal in the epilogue), i.e. at most one bf16 step apart."""
