@@ -449,6 +449,30 @@ def test_vae_fullsize_properties(dev, name):
     assert float((g_all - (g_a + g_b)).abs().max()) < 1e-3 * float(g_all.abs().max())   # atomics reorder sums only
 
 
+def test_vae_encoder_beyond_the_cluster_forms_address_range(dev):
+    """2700 windows of 96 steps at hidden 512: the stash of the encoder GRUs exceeds the 2 GiB that the eight-workgroup
+    sequence form addresses, so the first layer may not take the launch that multiplies its input itself (it has no
+    other form to fall back to inside the library): the engine forms the pre-activations and the plain kernels run.
+    The latents of the first windows equal those of a small batch of the same windows to the bf16 tolerance."""
+    s = dict(n_bins=0, n_cats=0, n_nums=7, cards=[])
+    sch = Schema(0, 0, 7, [])
+    B, T, L = 2700, 96, 6
+    ae = _make_vae(dict(H=512, E=128, L=L, seed=3), sch, dev, "bf16")
+    eng = ae.engine(dev)
+    data = fu.make_data(s, N=64, T=T, K=L, seed=4, mask_kind="ones")
+    x64 = T_(data["response"] + data["cond"], dev)
+    inp = x64.repeat(B // 64 + 1, 1, 1)[:B].contiguous()
+    eps = torch.zeros(B, T, L, device=dev)
+    z_big, mu_big, _ = eng.encoder(inp, eps, train=True)
+    from timeautodiff_amd import ops
+    assert not ops._lib.load().tad_last_kernel().decode().startswith("rnn_cluster"), "checked below through the values"
+    mu_big = mu_big[:64].clone()
+    z_small, mu_small, _ = eng.encoder(x64, eps[:64].contiguous(), train=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(mu_big).all()
+    assert fu.rel_err(mu_big.cpu().numpy(), mu_small.cpu().numpy()) < BF16_EMU_TOL
+
+
 # ------------------------------------------------------------------ bf16 loss-curve windows
 BF16_CURVE_TOL = 2e-2    # bf16 training loop vs the bf16-emulating oracle's loop, per-iteration loss, relative
 BF16_CURVE_REF_TOL = 5e-2   # bf16 training loop vs the fp32 reference's recorded curve, per-iteration loss, relative

@@ -514,7 +514,10 @@ class RnnStack:
             # ... and a first layer that reads few columns (the VAE's encoders: the table's features) multiplies them by
             # W_ih inside that form: no pre-activation tensor [B*T, ndir*4H] is written or read
             fused = None
-            if RNN_XIN and layer == 0 and wsb > 0 and self.mm16[0] and self.in_p(0) <= 32:
+            # (that form addresses its tensors with 32-bit byte offsets: where the widest of them, the stash of nd * 4H bf16
+            # columns, does not fit 2 GiB the launch is the plain one, which needs stored pre-activations)
+            addressable = (B + 128) * T * nd * H4 * 2 < (1 << 31)
+            if RNN_XIN and layer == 0 and wsb > 0 and addressable and self.mm16[0] and self.in_p(0) <= 32:
                 x16 = x if x.dtype == torch.bfloat16 else self._in16
                 if x16 is None:
                     x16 = ws.get(f"{tag}.in16", (BT, self.in_p(0)), dtype=torch.bfloat16, zero="new")
