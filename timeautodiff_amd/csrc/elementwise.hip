@@ -765,7 +765,7 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_fc_bwd_kernel(int64_t rows, int D
     fetch(r + nwaves);
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-      dp[k] = __shfl(mine, k, 64);
+      dp[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), k));      // (a scalar read: k is a constant here; a lane shuffle is a trip through the LDS crossbar)
       dpq[k] = round16 ? (float)(bf16_t)dp[k] : dp[k];
       dbk[k] += dp[k];
     }
